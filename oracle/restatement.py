@@ -1,0 +1,510 @@
+"""CPU oracle: a restatement of promonet's synthesis hot path in plain PyTorch.
+
+TEST INFRASTRUCTURE ONLY. Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import this module. The product
+(`promonet_amd`) never does: its compute runs in `libpromonet_hip.so`.
+
+Every function cites the reference file:line it follows (paths relative to
+`/root/reference`). Pinning status:
+
+* Generator / HiFi-GAN / prepare_features / prepare_global_features /
+  spectrogram.from_audio: PINNED. `oracle/make_golden.py` imports the real
+  reference in the build container, checks this restatement against it
+  (<= 1e-6) and commits the vectors under `tests/golden/`.
+* `ppgs.sparsify` (third-party `ppgs`, unpinned version, `setup.py:21`),
+  `librosa.filters.mel`, `librosa.stft`, `librosa.amplitude_to_db`,
+  `librosa.A_weighting` (third-party `librosa`, unpinned, `setup.py:17`):
+  PARITY UNPINNED. Neither package is installed or vendored; the functions
+  below restate their published algorithms and are anchored on the
+  reference's call sites only.
+
+All math is fp32 on CPU (`torch` ATen), the same op sequence the reference
+executes: un-fused conv1d / conv_transpose1d / leaky_relu / add.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+###############################################################################
+# Constants (promonet/config/defaults.py, promonet/config/static.py)
+###############################################################################
+
+SAMPLE_RATE = 22050          # defaults.py:49
+HOPSIZE = 256                # defaults.py:31
+NUM_FFT = 1024               # defaults.py:43
+WINDOW_SIZE = 1024           # defaults.py:52
+NUM_MELS = 80                # defaults.py:40
+FMIN = 50.                   # defaults.py:27
+FMAX = 550.                  # defaults.py:28
+MIN_DB = -100.               # defaults.py:37
+REF_DB = 20.                 # defaults.py:46
+LOUDNESS_BANDS = 8           # defaults.py:90
+PITCH_BINS = 256             # defaults.py:96
+PITCH_EMBEDDING_SIZE = 64    # defaults.py:99
+PPG_CHANNELS = 40
+SPARSE_PPG_THRESHOLD = 0.85  # defaults.py:117
+LRELU_SLOPE = .1             # defaults.py:216
+RESBLOCK_KERNEL_SIZES = (3, 7, 11)             # defaults.py:250
+RESBLOCK_DILATION_SIZES = ((1, 3, 5),) * 3     # defaults.py:253
+UPSAMPLE_INITIAL_SIZE = 512                    # defaults.py:256
+UPSAMPLE_KERNEL_SIZES = (16, 16, 4, 4)         # defaults.py:259
+UPSAMPLE_RATES = (8, 8, 2, 2)                  # defaults.py:262
+SPEAKER_CHANNELS = 256                         # defaults.py:265
+NUM_SPEAKERS = 109                             # static.py:62
+NUM_FEATURES = 113                             # static.py:48-53
+GLOBAL_CHANNELS = 258                          # static.py:42-45
+
+
+###############################################################################
+# Feature preparation
+###############################################################################
+
+
+def sparsify(ppg, method='percentile', threshold=SPARSE_PPG_THRESHOLD):
+    """`ppgs.sparsify` (third-party; called at model/generator.py:144-147).
+
+    PARITY UNPINNED: restated from the published interactiveaudiolab/ppgs
+    package. threshold = per-frame quantile (linear interpolation) over the
+    channel axis; entries <= threshold are zeroed; renormalise with
+    softmax(log(p + 1e-8)).
+    """
+    if not torch.is_tensor(threshold):
+        threshold = torch.tensor(threshold, dtype=ppg.dtype)
+    if method == 'percentile':
+        q = torch.quantile(ppg, threshold.to(ppg.dtype), dim=-2, keepdim=True)
+        ppg = torch.where(ppg > q, ppg, torch.zeros_like(ppg))
+    elif method == 'constant':
+        ppg = torch.where(ppg > threshold, ppg, torch.zeros_like(ppg))
+    else:
+        raise ValueError(f'Sparsify method {method} is not defined')
+    return torch.softmax(torch.log(ppg + 1e-8), -2)
+
+
+def band_average(loudness, bands=LOUDNESS_BANDS):
+    """preprocess/loudness.py:84-111 (and model/generator.py:172-180)."""
+    if bands is None:
+        return loudness
+    if bands == 1:
+        return loudness.mean(dim=-2, keepdim=True)
+    step = loudness.shape[-2] / bands
+    rows = [
+        loudness[..., int(b * step):int((b + 1) * step), :].mean(dim=-2)
+        for b in range(int(bands))]
+    return torch.stack(rows, dim=-2)
+
+
+def normalize(loudness):
+    """preprocess/loudness.py:144-146."""
+    return (loudness - MIN_DB) / (REF_DB - MIN_DB)
+
+
+def pitch_bins(pitch, pitch_distribution):
+    """model/generator.py:152-157: clip, searchsorted (right=False), clip."""
+    hz = torch.clip(pitch, FMIN, FMAX)
+    bins = torch.searchsorted(pitch_distribution, hz)
+    return torch.clip(bins, 0, PITCH_BINS - 1)
+
+
+def prepare_features(
+    loudness, pitch, periodicity, ppg, pitch_distribution, pitch_embedding,
+    ppg_threshold=SPARSE_PPG_THRESHOLD
+):
+    """model/generator.py:137-197 (hifigan branch, default config).
+
+    loudness (B, 8|513, T) dB; pitch (B, T) Hz; periodicity (B, T);
+    ppg (B, 40, T). Returns (B, 113, T) =
+    [ppg 0:40 | pitch-embedding 40:104 | loudness 104:112 | periodicity 112].
+    """
+    features = sparsify(ppg, 'percentile', ppg_threshold)
+    bins = pitch_bins(pitch, pitch_distribution)
+    embedded = F.embedding(bins, pitch_embedding).permute(0, 2, 1)
+    features = torch.cat((features, embedded), dim=1)
+    averaged = band_average(loudness, LOUDNESS_BANDS)
+    normalized = normalize(averaged)
+    if normalized.ndim == 2:
+        normalized = normalized[None]
+    features = torch.cat((features, normalized), dim=1)
+    return torch.cat((features, periodicity[:, None]), dim=1)
+
+
+def prepare_global_features(
+    speakers, spectral_balance_ratios, loudness_ratios, speaker_embedding
+):
+    """model/generator.py:49-70 (AUGMENT_PITCH and AUGMENT_LOUDNESS on)."""
+    g = F.embedding(speakers, speaker_embedding).unsqueeze(-1)
+    g = torch.cat((g, spectral_balance_ratios[:, None, None]), dim=1)
+    return torch.cat((g, loudness_ratios[:, None, None]), dim=1)
+
+
+###############################################################################
+# HiFi-GAN generator from a reference-keyed state dict
+###############################################################################
+
+
+def get_padding(kernel_size, dilation=1, stride=1):
+    """model/core.py:9-11."""
+    return int((kernel_size * dilation - dilation - stride + 1) / 2)
+
+
+def fold_weight_norm(g, v):
+    """torch.nn.utils.weight_norm, dim=0: w = g * v / ||v|| over dims != 0.
+
+    For ConvTranspose1d dim 0 is the INPUT channel (weight_g (C_in, 1, 1)).
+    Reference: model/core.py:43-45, model/hifigan.py:100-106 (hooks recompute
+    this every forward; model/generator.py:203-206 removes them on export).
+    """
+    norm = torch.linalg.vector_norm(v, ord=2, dim=(1, 2), keepdim=True)
+    return v * (g / norm)
+
+
+def folded_state(state):
+    """Return {name: tensor} with every weight_g/weight_v pair folded."""
+    out = {}
+    for key, value in state.items():
+        if key.endswith('.weight_g'):
+            base = key[:-len('.weight_g')]
+            out[base + '.weight'] = fold_weight_norm(
+                value, state[base + '.weight_v'])
+        elif key.endswith('.weight_v'):
+            continue
+        else:
+            out[key] = value
+    return out
+
+
+def hifigan_config(state):
+    """Derive (initial_channels, rates, kernel sizes) from tensor shapes."""
+    initial = state['model.input_feature_conv.weight'].shape[0]
+    rates, kernels = [], []
+    i = 0
+    while f'model.model.{i}.model.1.bias' in state:
+        key = f'model.model.{i}.model.1.weight'
+        w = state[key] if key in state else state[key + '_v']
+        kernels.append(w.shape[2])
+        i += 1
+    # stride is not recoverable from shapes alone; k == 2 * r in every
+    # reference config (defaults.py:259-262)
+    rates = [k // 2 for k in kernels]
+    return initial, tuple(rates), tuple(kernels)
+
+
+def block(x, w, prefix, kernel_size, dilations, trace=None):
+    """model/hifigan.py:198-210."""
+    for n, d in enumerate(dilations):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        xt = F.conv1d(
+            xt, w[f'{prefix}.convs1.{n}.weight'], w[f'{prefix}.convs1.{n}.bias'],
+            padding=get_padding(kernel_size, d), dilation=d)
+        xt = F.leaky_relu(xt, LRELU_SLOPE)
+        xt = F.conv1d(
+            xt, w[f'{prefix}.convs2.{n}.weight'], w[f'{prefix}.convs2.{n}.bias'],
+            padding=get_padding(kernel_size, 1))
+        x = xt + x
+        if trace is not None:
+            trace[f'{prefix}.iter{n}'] = x
+    return x
+
+
+def residual_block(x, w, prefix, trace=None):
+    """model/hifigan.py:141-145: sum of the three Blocks / 3."""
+    xs = None
+    for j, (k, d) in enumerate(
+            zip(RESBLOCK_KERNEL_SIZES, RESBLOCK_DILATION_SIZES)):
+        y = block(x, w, f'{prefix}.model.{j}', k, d, trace)
+        xs = y if xs is None else xs + y
+    return xs / len(RESBLOCK_KERNEL_SIZES)
+
+
+def hifigan_forward(features, global_features, state, trace=None):
+    """model/hifigan.py:63-70 with weights from a reference-keyed state dict.
+
+    `state` keys are prefixed `model.` (the Generator's attribute name for
+    the vocoder, model/generator.py:22). Accepts weight-normed or folded
+    tensors. features (B, 113, T), global_features (B|1, 258, 1) ->
+    (B, 1, 256 T).
+    """
+    w = folded_state(state)
+    _, rates, kernels = hifigan_config(w)
+    x = F.conv1d(
+        features, w['model.input_feature_conv.weight'],
+        w['model.input_feature_conv.bias'], padding=3)
+    x = x + F.conv1d(
+        global_features, w['model.input_speaker_conv.weight'],
+        w['model.input_speaker_conv.bias'])
+    if trace is not None:
+        trace['input'] = x
+    for i, (r, k) in enumerate(zip(rates, kernels)):
+        x = F.leaky_relu(x, LRELU_SLOPE)
+        x = F.conv_transpose1d(
+            x, w[f'model.model.{i}.model.1.weight'],
+            w[f'model.model.{i}.model.1.bias'], stride=r,
+            padding=(k - r) // 2)
+        if trace is not None:
+            trace[f'upsample{i}'] = x
+        x = residual_block(x, w, f'model.model.{i}.model.2', trace)
+        if trace is not None:
+            trace[f'mrf{i}'] = x
+    n = len(rates)
+    x = F.leaky_relu(x, LRELU_SLOPE)
+    x = F.conv1d(x, w[f'model.model.{n + 1}.weight'], None, padding=3)
+    return torch.tanh(x)
+
+
+def generator_forward(
+    loudness, pitch, periodicity, ppg, speakers, spectral_balance_ratios,
+    loudness_ratios, state, trace=None
+):
+    """model/generator.py:116-135 (`previous_samples` is unused by HiFi-GAN,
+    model/hifigan.py:63)."""
+    features = prepare_features(
+        loudness, pitch, periodicity, ppg, state['pitch_distribution'],
+        state['pitch_embedding.weight'], state['ppg_threshold'])
+    global_features = prepare_global_features(
+        speakers, spectral_balance_ratios, loudness_ratios,
+        state['speaker_embedding.weight'])
+    if trace is not None:
+        trace['features'] = features
+        trace['global_features'] = global_features
+    return hifigan_forward(features, global_features, state, trace)
+
+
+def from_features(
+    loudness, pitch, periodicity, ppg, state, speaker=0,
+    spectral_balance_ratio=1., loudness_ratio=1.
+):
+    """synthesize/core.py:18-59 + generate :209-281 on CPU: returns item 0
+    of the batch, shape (1, 256 T), float32."""
+    if loudness.ndim == 2:
+        loudness = loudness[None]
+    speakers = torch.full((1,), speaker, dtype=torch.long)
+    sbr = torch.tensor([spectral_balance_ratio], dtype=torch.float)
+    lr = torch.tensor([loudness_ratio], dtype=torch.float)
+    with torch.inference_mode():
+        return generator_forward(
+            loudness, pitch, periodicity, ppg, speakers, sbr, lr,
+            state)[0].to(torch.float32)
+
+
+###############################################################################
+# Random-init weights exactly as the reference constructs them
+###############################################################################
+
+
+def random_state(seed=0, initial_channels=UPSAMPLE_INITIAL_SIZE,
+                 pitch_distribution=None, folded=False):
+    """Build a reference-keyed state dict with the reference's init scheme.
+
+    NOT bit-identical to `torch.manual_seed(seed); Generator()` (module
+    construction order consumes the RNG differently); the goldens that need
+    the reference's exact tensors carry them. Distributions follow
+    model/hifigan.py:19-61,220-223 (weight-normed convs: v ~ N(0, 0.01),
+    g = ||v||; torch defaults elsewhere).
+    """
+    gen = torch.Generator().manual_seed(seed)
+
+    def normal(*shape, std=1.):
+        return torch.randn(*shape, generator=gen) * std
+
+    def uniform(*shape, bound):
+        return (torch.rand(*shape, generator=gen) * 2 - 1) * bound
+
+    state = {}
+    state['default_previous_samples'] = torch.zeros(1, 1, 1)
+    state['ppg_threshold'] = torch.tensor(SPARSE_PPG_THRESHOLD)
+    if pitch_distribution is None:
+        pitch_distribution = torch.exp(torch.linspace(
+            math.log(55.9431), math.log(547.3264), PITCH_BINS))
+    state['pitch_distribution'] = pitch_distribution.clone().float()
+    state['speaker_embedding.weight'] = normal(NUM_SPEAKERS, SPEAKER_CHANNELS)
+    state['pitch_embedding.weight'] = normal(PITCH_BINS, PITCH_EMBEDDING_SIZE)
+
+    c0 = initial_channels
+    bound = 1 / math.sqrt(NUM_FEATURES * 7)
+    state['model.input_feature_conv.weight'] = uniform(
+        c0, NUM_FEATURES, 7, bound=bound)
+    state['model.input_feature_conv.bias'] = uniform(c0, bound=bound)
+    bound = 1 / math.sqrt(GLOBAL_CHANNELS)
+    state['model.input_speaker_conv.weight'] = uniform(
+        c0, GLOBAL_CHANNELS, 1, bound=bound)
+    state['model.input_speaker_conv.bias'] = uniform(c0, bound=bound)
+
+    def weight_normed(prefix, v, bias_bound):
+        g = torch.linalg.vector_norm(v, ord=2, dim=(1, 2), keepdim=True)
+        state[prefix + '.bias'] = uniform(v.shape[0] if 'convs' in prefix
+                                          else v.shape[1], bound=bias_bound)
+        state[prefix + '.weight_g'] = g
+        state[prefix + '.weight_v'] = v
+
+    for i, (r, k) in enumerate(zip(UPSAMPLE_RATES, UPSAMPLE_KERNEL_SIZES)):
+        cin, cout = c0 // 2 ** i, c0 // 2 ** (i + 1)
+        # ConvTranspose1d fan_in = weight.size(1) * k = cout * k
+        weight_normed(
+            f'model.model.{i}.model.1', normal(cin, cout, k, std=.01),
+            1 / math.sqrt(cout * k))
+        for j, ks in enumerate(RESBLOCK_KERNEL_SIZES):
+            for name in ('convs1', 'convs2'):
+                for n in range(3):
+                    weight_normed(
+                        f'model.model.{i}.model.2.model.{j}.{name}.{n}',
+                        normal(cout, cout, ks, std=.01),
+                        1 / math.sqrt(cout * ks))
+    n = len(UPSAMPLE_RATES)
+    cl = c0 // 2 ** n
+    state[f'model.model.{n + 1}.weight'] = uniform(
+        1, cl, 7, bound=1 / math.sqrt(cl * 7))
+    return folded_state(state) if folded else state
+
+
+def synthetic_inputs(batch, frames, seed=1234, loudness_rows=8):
+    """SURVEY.md section 8(d) / BASELINE.md section 4 synthetic workload."""
+    gen = torch.Generator().manual_seed(seed)
+    loudness = torch.rand(
+        batch, loudness_rows, frames, generator=gen) * 80. - 100.
+    pitch = torch.exp(
+        torch.rand(batch, frames, generator=gen) *
+        (math.log(550.) - math.log(50.)) + math.log(50.))
+    periodicity = torch.rand(batch, frames, generator=gen)
+    ppg = torch.softmax(
+        3. * torch.randn(batch, PPG_CHANNELS, frames, generator=gen), dim=1)
+    speakers = torch.arange(batch) % NUM_SPEAKERS
+    ones = torch.ones(batch)
+    return loudness, pitch, periodicity, ppg, speakers, ones, ones.clone()
+
+
+###############################################################################
+# STFT / mel / loudness preprocessing
+###############################################################################
+
+
+def spectrogram(audio, mels=False, threshold=None):
+    """preprocess/spectrogram.py:15-60. audio (B,1,N)|(1,N) ->
+    (B,513,N//256) (squeeze(0) when B == 1)."""
+    window = torch.hann_window(WINDOW_SIZE, dtype=audio.dtype)
+    size = (NUM_FFT - HOPSIZE) // 2
+    audio = F.pad(audio, (size, size), mode='reflect')
+    stft = torch.stft(
+        audio.squeeze(1), NUM_FFT, hop_length=HOPSIZE, window=window,
+        center=False, normalized=False, onesided=True, return_complex=True)
+    stft = torch.view_as_real(stft)
+    spec = torch.sqrt(stft.pow(2).sum(-1) + 1e-6)
+    if mels:
+        spec = linear_to_mel(spec, threshold)
+    return spec.squeeze(0)
+
+
+def spectrogram_dft(audio):
+    """Same quantity as `spectrogram` via an explicit float64 framed DFT
+    (independent check of the framing/reflect-pad/window conventions)."""
+    a = audio.reshape(-1, audio.shape[-1]).double()
+    size = (NUM_FFT - HOPSIZE) // 2
+    a = F.pad(a[:, None], (size, size), mode='reflect')[:, 0]
+    frames = a.unfold(-1, NUM_FFT, HOPSIZE)
+    window = torch.hann_window(WINDOW_SIZE, dtype=torch.float64)
+    n = torch.arange(NUM_FFT, dtype=torch.float64)
+    k = torch.arange(NUM_FFT // 2 + 1, dtype=torch.float64)
+    angle = 2 * math.pi * k[:, None] * n[None] / NUM_FFT
+    re = torch.einsum('btn,kn->bkt', frames * window, torch.cos(angle))
+    im = torch.einsum('btn,kn->bkt', frames * window, -torch.sin(angle))
+    return torch.sqrt(re * re + im * im + 1e-6)
+
+
+def hz_to_mel_slaney(f):
+    f = np.asanyarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    with np.errstate(divide='ignore', invalid='ignore'):
+        log_t = min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep
+    return np.where(f >= min_log_hz, log_t, mels)
+
+
+def mel_to_hz_slaney(m):
+    m = np.asanyarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    freqs = f_sp * m
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(
+        m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)),
+        freqs)
+
+
+def mel_basis(sr=SAMPLE_RATE, n_fft=NUM_FFT, n_mels=NUM_MELS):
+    """`librosa.filters.mel(sr, n_fft, n_mels)` defaults (fmin 0, fmax sr/2,
+    htk False, norm 'slaney', float32); called at
+    preprocess/spectrogram.py:118-121. PARITY UNPINNED (librosa absent)."""
+    fftfreqs = np.linspace(0, sr / 2, 1 + n_fft // 2)
+    mel_f = mel_to_hz_slaney(np.linspace(
+        hz_to_mel_slaney(0.0), hz_to_mel_slaney(sr / 2), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, None]
+    return torch.from_numpy(weights.astype(np.float32))
+
+
+def linear_to_mel(spec, threshold=None):
+    """preprocess/spectrogram.py:111-133: log(mel_basis @ spec)."""
+    mel = torch.log(torch.matmul(mel_basis().to(spec.dtype), spec))
+    if threshold is not None:
+        return torch.clamp(mel, min=threshold)
+    return mel
+
+
+def a_weighting(frequencies, min_db=-80.0):
+    """`librosa.A_weighting` (IEC 61672), PARITY UNPINNED."""
+    f_sq = np.asanyarray(frequencies, dtype=np.float64) ** 2.0
+    const = np.array([12194.217, 20.598997, 107.65265, 737.86223]) ** 2.0
+    with np.errstate(divide='ignore'):
+        weights = 2.0 + 20.0 * (
+            np.log10(const[0]) + 2 * np.log10(f_sq) -
+            np.log10(f_sq + const[0]) - np.log10(f_sq + const[1]) -
+            0.5 * np.log10(f_sq + const[2]) - 0.5 * np.log10(f_sq + const[3]))
+    return np.maximum(min_db, weights)
+
+
+def perceptual_weights():
+    """preprocess/loudness.py:149-160: A_weighting(fft_frequencies) - REF_DB,
+    shape (513, 1), float64 as numpy returns it."""
+    freqs = np.linspace(0, SAMPLE_RATE / 2, 1 + WINDOW_SIZE // 2)
+    return a_weighting(freqs)[:, None] - float(REF_DB)
+
+
+def loudness(audio, bands=1):
+    """preprocess/loudness.py:17-55. audio (1, N) -> (bands|513, N // 256).
+
+    librosa.stft(center=False, hann periodic) -> complex64;
+    amplitude_to_db(|S|): 20 log10(max(1e-5, |S|)) floored at max - 80 over
+    the whole utterance; + A-weights - 20; floor at MIN_DB.
+    """
+    padding = (WINDOW_SIZE - HOPSIZE) // 2
+    x = F.pad(audio[None], (padding, padding), mode='reflect').squeeze(0)
+    x = x.detach().cpu().numpy().squeeze(0)
+    window = torch.hann_window(WINDOW_SIZE, dtype=torch.float64).numpy()
+    frames = np.lib.stride_tricks.sliding_window_view(
+        x, WINDOW_SIZE)[::HOPSIZE]
+    dtype = np.complex64 if x.dtype == np.float32 else np.complex128
+    stft = np.fft.rfft(
+        frames * window.astype(x.dtype), axis=-1).T.astype(dtype)
+    magnitude = np.abs(stft)
+    # librosa.amplitude_to_db(S) = power_to_db(|S|**2, ref=1, amin=1e-10,
+    # top_db=80): 10 log10(max(amin, |S|^2)) - 10 log10(max(amin, 1))
+    amin, top_db = 1e-5, 80.0
+    power = np.square(magnitude)
+    db = 10.0 * np.log10(np.maximum(amin ** 2, power))
+    db -= 10.0 * np.log10(np.maximum(amin ** 2, 1.0))
+    db = np.maximum(db, db.max() - top_db)
+    weighted = db + perceptual_weights()
+    weighted[weighted < MIN_DB] = MIN_DB
+    out = torch.from_numpy(weighted).float()
+    return band_average(out, bands) if bands is not None else out
