@@ -1,0 +1,22 @@
+# Build libpromonet_hip.so (gfx950) and nothing else. `make -j4`.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CXXFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude
+SRC = promonet_amd/csrc
+OBJ = build/obj
+LIB = promonet_amd/lib/libpromonet_hip.so
+OBJS = $(OBJ)/pm_api.o $(OBJ)/pm_conv_f16.o $(OBJ)/pm_conv_bf16.o $(OBJ)/pm_conv_f32.o
+HDRS = $(wildcard $(SRC)/*.h) include/promonet_hip.h
+
+all: $(LIB)
+
+$(OBJ)/%.o: $(SRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p promonet_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+
+clean:
+	rm -rf build $(LIB)

@@ -1,0 +1,202 @@
+/* promonet_hip.h - C ABI of libpromonet_hip.so
+ *
+ * MI355X (gfx950 / CDNA4) implementation of promonet's synthesis hot path.
+ * The reference (maxrmorrison/promonet @ 2024_08_07) is 100 % Python on
+ * PyTorch and has NO FFI / plugin interface of its own; the seams this
+ * library attaches to are Python module methods. Each entry point cites the
+ * reference code it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - C linkage, plain pointers and sizes, no torch types.
+ *   - Every pointer named *dev* / every tensor argument is a DEVICE pointer
+ *     owned by the caller (e.g. torch.Tensor.data_ptr()); never mutated
+ *     unless documented as an output.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream). All
+ *     compute entry points are asynchronous on that stream.
+ *   - Return value: PM_OK (0) or a negative PM_E* code; pm_last_error()
+ *     returns a thread-local human-readable message for the last failure.
+ *   - No allocation inside the forward path: the caller passes a workspace
+ *     whose size comes from pm_hifigan_workspace_bytes(). Weight storage is
+ *     allocated at load time (pm_hifigan_load_tensor / pm_hifigan_finalize).
+ *   - fp32 tensors are dense row-major in the reference's (PyTorch) layout:
+ *     activations (B, C, T), conv weights (C_out, C_in, k), transposed-conv
+ *     weights (C_in, C_out, k). Arguments suffixed `_cl` are the library's
+ *     internal channels-last layout (B, T, C_pad), C_pad = round_up(C, 32).
+ */
+#ifndef PROMONET_HIP_H
+#define PROMONET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_OK 0
+#define PM_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define PM_ESTATE (-2)      /* call order (e.g. forward before finalize)  */
+#define PM_EHIP (-3)        /* a HIP runtime call failed                   */
+#define PM_ENOMEM (-4)      /* workspace too small / allocation failed     */
+
+/* MFMA operand type (accumulation is always fp32; activations between
+ * kernels are always fp32 in HBM) */
+#define PM_F32 0            /* v_mfma_f32_32x32x2_f32   - exact fp32       */
+#define PM_F16 1            /* v_mfma_f32_32x32x16_f16                     */
+#define PM_BF16 2           /* v_mfma_f32_32x32x16_bf16                    */
+
+#define PM_MAX_STAGES 8
+#define PM_MAX_RESBLOCKS 4
+#define PM_MAX_DILATIONS 4
+
+typedef struct pm_hifigan_s* pm_hifigan_t;
+
+/* Mirrors the constants the reference reads at import time:
+ * promonet/config/defaults.py:216,250-262 and config/static.py:42-53.   */
+typedef struct pm_hifigan_config {
+    int num_features;                 /* NUM_FEATURES (113)                */
+    int global_channels;              /* GLOBAL_CHANNELS (258)             */
+    int initial_channels;             /* HIFIGAN_UPSAMPLE_INITIAL_SIZE     */
+    int num_stages;                   /* len(HIFIGAN_UPSAMPLE_RATES)       */
+    int upsample_rates[PM_MAX_STAGES];
+    int upsample_kernel_sizes[PM_MAX_STAGES];
+    int num_resblocks;                /* len(HIFIGAN_RESBLOCK_KERNEL_SIZES)*/
+    int resblock_kernel_sizes[PM_MAX_RESBLOCKS];
+    int num_dilations;
+    int resblock_dilations[PM_MAX_RESBLOCKS][PM_MAX_DILATIONS];
+    int compute_dtype;                /* PM_F32 | PM_F16 | PM_BF16         */
+} pm_hifigan_config;
+
+int pm_version(void);
+const char* pm_last_error(void);
+
+/* ---- HiFi-GAN vocoder engine: replaces promonet.model.HiFiGAN ----------
+ * (promonet/model/hifigan.py:13-77; constructed at generator.py:22-25)   */
+int pm_hifigan_create(const pm_hifigan_config* config, pm_hifigan_t* out);
+int pm_hifigan_destroy(pm_hifigan_t h);
+
+/* Load one tensor of HiFiGAN.state_dict() by its reference key, e.g.
+ *   input_feature_conv.weight (512,113,7)   input_speaker_conv.bias (512)
+ *   model.0.model.1.weight_g (512,1,1)      model.0.model.1.weight_v (512,256,16)
+ *   model.0.model.2.model.1.convs2.0.bias   model.5.weight (1,32,7)
+ * Weight-normed layers accept either the (weight_g, weight_v) pair of the
+ * checkpoint (folded here: w = g v / ||v||, replacing the per-forward
+ * torch.nn.utils.weight_norm hook of model/core.py:43-45) or an already
+ * folded `.weight`. Replaces torchutil.checkpoint.load -> load_state_dict
+ * at promonet/synthesize/core.py:245. Synchronous w.r.t. `stream`.       */
+int pm_hifigan_load_tensor(pm_hifigan_t h, const char* name,
+                           const float* dev, const int64_t* shape, int ndim,
+                           void* stream);
+/* Verify every tensor is present; must precede forward.                  */
+int pm_hifigan_finalize(pm_hifigan_t h, void* stream);
+
+size_t pm_hifigan_workspace_bytes(pm_hifigan_t h, int batch, int frames);
+int pm_hifigan_hopsize(pm_hifigan_t h);
+int pm_hifigan_features_cl_channels(pm_hifigan_t h);
+
+/* HiFiGAN.forward(x, g, p) (hifigan.py:63-70):
+ *   features (B, num_features, T) fp32, global_features (Bg, global_channels)
+ *   with Bg == 1 (broadcast) or B; out (B, 1, T * hop) fp32.              */
+int pm_hifigan_forward(pm_hifigan_t h, const float* features,
+                       const float* global_features, int global_batch,
+                       float* out, int batch, int frames, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* Same with the features already channels-last (B, T, C_pad) - what
+ * pm_prepare_features writes.                                             */
+int pm_hifigan_forward_cl(pm_hifigan_t h, const float* features_cl,
+                          const float* global_features, int global_batch,
+                          float* out, int batch, int frames, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* Optional per-launch timing (HIP events recorded on `stream` around every
+ * kernel the forward launches; no reference counterpart - the reference only
+ * has wall-clock torchutil timers, synthesize/core.py:222,250). collect()
+ * synchronises and folds the recorded pairs into per-label totals; report()
+ * returns "label launches total_ms algorithmic_flops algorithmic_bytes" lines. */
+int pm_hifigan_profile_enable(pm_hifigan_t h, int enable);
+int pm_hifigan_profile_collect(pm_hifigan_t h);
+int pm_hifigan_profile_reset(pm_hifigan_t h);
+const char* pm_hifigan_profile_report(pm_hifigan_t h);
+
+/* ---- conditioning: replaces Generator.prepare_features ------------------
+ * (promonet/model/generator.py:137-197, default config) incl. the
+ * third-party ppgs.sparsify('percentile') it calls (:140-147).
+ *   loudness (B, F, T) dB with F == bands or any F >= bands (513)
+ *   pitch (B, T) Hz, periodicity (B, T), ppg (B, P, T)
+ *   pitch_edges (NB) = Generator.pitch_distribution, pitch_table (NB, E)
+ *   out_ref (B, P+E+bands+1, T) and/or out_cl (B, T, C_pad); either may be
+ *   NULL.                                                                 */
+int pm_prepare_features(const float* loudness, const float* pitch,
+                        const float* periodicity, const float* ppg,
+                        const float* pitch_edges, const float* pitch_table,
+                        float* out_ref, float* out_cl, int batch, int frames,
+                        int loudness_rows, int ppg_channels, int pitch_bins,
+                        int embedding_size, int bands, int cl_channels,
+                        float ppg_threshold, float fmin, float fmax,
+                        float min_db, float ref_db, void* stream);
+
+/* BaseGenerator.prepare_global_features (generator.py:49-70): speaker
+ * embedding lookup + the two augmentation ratios -> (B, S + 2).           */
+int pm_prepare_global_features(const int64_t* speakers,
+                               const float* spectral_balance_ratios,
+                               const float* loudness_ratios,
+                               const float* speaker_table, float* out,
+                               int batch, int speaker_channels, void* stream);
+
+/* ---- per-kernel entry points (unit parity tests; weights in torch layout,
+ * packed into `workspace` on every call) --------------------------------- */
+size_t pm_op_workspace_bytes(int c_in, int c_out, int k);
+/* One Block iteration (hifigan.py:204-210), channels-last fp32 in/out:
+ *   y = x + conv2(lrelu(conv1(lrelu(x)))); mode 0: out = y,
+ *   1: out = y * scale, 2: out += y * scale                               */
+int pm_block_iteration_cl(int dtype, const float* x_cl, float* out_cl,
+                          const float* w1, const float* b1, const float* w2,
+                          const float* b2, int batch, int length,
+                          int channels, int kernel_size, int dilation,
+                          int mode, float scale, void* workspace,
+                          size_t workspace_bytes, void* stream);
+/* lrelu(optional) -> ConvTranspose1d(c_in, c_out, k = 2 r, stride r,
+ * padding r / 2) (hifigan.py:97-106), channels-last: (B, L, c_in_pad) ->
+ * (B, L * r, c_out_pad)                                                   */
+int pm_conv_transpose_cl(int dtype, const float* x_cl, float* out_cl,
+                         const float* w, const float* bias, int batch,
+                         int length, int c_in, int c_out, int rate, int lrelu,
+                         void* workspace, size_t workspace_bytes,
+                         void* stream);
+/* LeakyReLU -> Conv1d(C, 1, 7, pad 3, no bias) -> tanh (hifigan.py:55-60):
+ * (B, L, c_pad) channels-last -> (B, L)                                   */
+int pm_out_conv_tanh(const float* x_cl, const float* w, float* out,
+                     int batch, int length, int channels, void* stream);
+/* torch.nn.utils.weight_norm fold: w = g * v / ||v||, rows x cols        */
+int pm_fold_weight_norm(const float* g, const float* v, float* w, int rows,
+                        int cols, void* stream);
+/* (B, C, T) -> (B, T, c_pad) zero padded, and back                        */
+int pm_to_channels_last(const float* src, float* dst, int batch, int channels,
+                        int frames, int c_pad, void* stream);
+
+/* ---- preprocessing: promonet/preprocess/spectrogram.py, loudness.py ---- */
+/* spectrogram.from_audio (spectrogram.py:15-60): reflect-pad 384, hann-1024
+ * hop-256 framed DFT, sqrt(re^2 + im^2 + 1e-6): audio (B, N) ->
+ * (B, 513, N / 256)                                                       */
+size_t pm_stft_scratch_bytes(int batch, int samples);
+int pm_stft_magnitude(const float* audio, float* out, int batch, int samples,
+                      void* scratch, size_t scratch_bytes, void* stream);
+/* spectrogram.linear_to_mel (spectrogram.py:111-133): log(basis @ spec),
+ * optional clamp: spec (B, F, T), basis (Mel, F) -> (B, Mel, T)           */
+int pm_linear_to_mel(const float* spec, const float* basis, float* out,
+                     int batch, int bins, int mels, int frames,
+                     int use_threshold, float log_threshold, void* stream);
+/* loudness.from_audio (loudness.py:17-55) per utterance: A-weighted dB with
+ * the utterance-global (max - 80 dB) floor of librosa.amplitude_to_db, then
+ * band_average (loudness.py:84-111): audio (B, N) -> (B, bands, N / 256);
+ * a_weights (513) = perceptual_weights() (loudness.py:149-160);
+ * scratch: pm_loudness_scratch_bytes()                                     */
+size_t pm_loudness_scratch_bytes(int batch, int samples);
+int pm_loudness(const float* audio, const float* a_weights, float* out,
+                int batch, int samples, int bands, float min_db,
+                void* scratch, size_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROMONET_HIP_H */

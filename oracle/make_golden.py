@@ -1,0 +1,155 @@
+"""Generate the committed golden vectors under tests/golden/ by importing the
+REAL reference (`/root/reference/promonet`, stubbed third-party deps) in the
+build container, and check the CPU restatement against it while doing so.
+
+TEST INFRASTRUCTURE ONLY - runs only where /root/reference exists:
+
+    python oracle/make_golden.py            # both configs (two subprocesses)
+
+Fixtures are data: inputs, reference-constructed weights (small config only)
+and the reference's outputs. No reference source is copied.
+"""
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / 'tests' / 'golden'
+sys.path.insert(0, str(ROOT / 'oracle'))
+
+
+def small_config_file():
+    file = Path(tempfile.gettempdir()) / 'promonet_small_config.py'
+    file.write_text(
+        "MODULE = 'promonet'\nCONFIG = 'small'\n"
+        "HIFIGAN_UPSAMPLE_INITIAL_SIZE = 64\n")
+    return file
+
+
+def run(which):
+    import torch
+    import reference_import
+    import restatement as oracle
+
+    configs = [small_config_file()] if which == 'small' else []
+    promonet = reference_import.load(configs)
+    torch.manual_seed(0)
+    GOLDEN.mkdir(parents=True, exist_ok=True)
+
+    if which == 'small':
+        assert promonet.HIFIGAN_UPSAMPLE_INITIAL_SIZE == 64
+        model = promonet.model.Generator().eval()
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        inputs = oracle.synthetic_inputs(2, 24, seed=11)
+        with torch.inference_mode():
+            features = model.prepare_features(*inputs[:4])
+            global_features = model.prepare_global_features(*inputs[4:7])
+            audio = model(*inputs, model.default_previous_samples)
+            mine = oracle.generator_forward(*inputs, state)
+        error = (audio - mine).abs().max().item()
+        print(f'small: restatement vs reference max-abs {error:.3e}')
+        assert error < 1e-6
+        torch.save({
+            'config': {'HIFIGAN_UPSAMPLE_INITIAL_SIZE': 64},
+            'state': state,
+            'inputs': inputs,
+            'features': features,
+            'global_features': global_features,
+            'audio': audio}, GOLDEN / 'generator_small.pt')
+        return
+
+    # ---- default configuration ------------------------------------------
+    model = promonet.model.Generator().eval()
+    reference_state = model.state_dict()
+    # weights regenerated from a seed on both sides (57 MB is too big to
+    # commit): restatement-defined init, loaded INTO the reference module
+    state = oracle.random_state(seed=0)
+    state['pitch_distribution'] = reference_state['pitch_distribution'].clone()
+    model.load_state_dict(state)
+    golden = {'seed': 0, 'input_seed': 1234,
+              'pitch_distribution': state['pitch_distribution'].clone()}
+
+    for name, (batch, frames) in {'b2_t40': (2, 40), 'b1_t7': (1, 7)}.items():
+        inputs = oracle.synthetic_inputs(batch, frames, seed=1234)
+        with torch.inference_mode():
+            audio = model(*inputs, model.default_previous_samples)
+            mine = oracle.generator_forward(*inputs, state)
+        error = (audio - mine).abs().max().item()
+        print(f'{name}: restatement vs reference max-abs {error:.3e}')
+        assert error < 1e-6
+        golden[name] = {'batch': batch, 'frames': frames, 'audio': audio}
+
+    # synthesize.from_features through the reference's public API (B = 1)
+    promonet.synthesize.generate.model = model
+    promonet.synthesize.generate.checkpoint = None
+    promonet.synthesize.generate.device = torch.device('cpu')
+    inputs = oracle.synthetic_inputs(1, 12, seed=99)
+    api = promonet.synthesize.from_features(
+        inputs[0][0], inputs[1], inputs[2], inputs[3], speaker=3,
+        spectral_balance_ratio=1.25, loudness_ratio=.8)
+    mine = oracle.from_features(
+        inputs[0][0], inputs[1], inputs[2], inputs[3], state, 3, 1.25, .8)
+    assert api.shape == (1, 12 * 256) and (api - mine).abs().max() < 1e-6
+    golden['from_features'] = {
+        'frames': 12, 'input_seed': 99, 'speaker': 3,
+        'spectral_balance_ratio': 1.25, 'loudness_ratio': .8, 'audio': api}
+
+    # prepare_features: 8-row and 513-row loudness
+    inputs = oracle.synthetic_inputs(2, 24, seed=5)
+    wide = oracle.synthetic_inputs(2, 24, seed=5, loudness_rows=513)[0]
+    with torch.inference_mode():
+        golden['features'] = {
+            'frames': 24, 'input_seed': 5,
+            'rows8': model.prepare_features(*inputs[:4]),
+            'rows513': model.prepare_features(wide, *inputs[1:4]),
+            'global': model.prepare_global_features(*inputs[4:7])}
+        for key, rows in (('rows8', inputs[0]), ('rows513', wide)):
+            mine = oracle.prepare_features(
+                rows, *inputs[1:4], state['pitch_distribution'],
+                state['pitch_embedding.weight'], state['ppg_threshold'])
+            assert (mine - golden['features'][key]).abs().max() < 1e-6
+
+    # spectrogram.from_audio (torch.stft inside the reference)
+    gen = torch.Generator().manual_seed(7)
+    one = torch.randn(1, 5120, generator=gen) * .1
+    many = torch.randn(3, 1, 2560, generator=gen) * .1
+    with torch.inference_mode():
+        golden['spectrogram'] = {
+            'one_input': one, 'many_input': many,
+            'one': promonet.preprocess.spectrogram.from_audio(one),
+            'many': promonet.preprocess.spectrogram.from_audio(many)}
+    assert golden['spectrogram']['one'].shape == (513, 20)
+    assert golden['spectrogram']['many'].shape == (3, 513, 10)
+    for key in ('one', 'many'):
+        mine = oracle.spectrogram(golden['spectrogram'][key + '_input'])
+        assert (mine - golden['spectrogram'][key]).abs().max() < 1e-6
+        dft = oracle.spectrogram_dft(golden['spectrogram'][key + '_input'])
+        assert (dft - golden['spectrogram'][key].double().reshape(
+            dft.shape)).abs().max() < 2e-5
+
+    # import-time constants the host mirror must reproduce
+    golden['constants'] = {
+        key: getattr(promonet, key) for key in (
+            'NUM_FEATURES', 'GLOBAL_CHANNELS', 'NUM_SPEAKERS',
+            'NUM_PREVIOUS_SAMPLES', 'SAMPLE_RATE', 'HOPSIZE', 'NUM_FFT',
+            'WINDOW_SIZE', 'NUM_MELS', 'FMIN', 'FMAX', 'MIN_DB', 'REF_DB',
+            'LOUDNESS_BANDS', 'PITCH_BINS', 'PITCH_EMBEDDING_SIZE',
+            'PPG_CHANNELS', 'SPARSE_PPG_THRESHOLD', 'LRELU_SLOPE',
+            'HIFIGAN_RESBLOCK_KERNEL_SIZES', 'HIFIGAN_RESBLOCK_DILATION_SIZES',
+            'HIFIGAN_UPSAMPLE_INITIAL_SIZE', 'HIFIGAN_UPSAMPLE_KERNEL_SIZES',
+            'HIFIGAN_UPSAMPLE_RATES', 'SPEAKER_CHANNELS')}
+    golden['state_keys'] = {
+        k: tuple(v.shape) for k, v in reference_state.items()}
+    torch.save(golden, GOLDEN / 'generator_default.pt')
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1:
+        run(sys.argv[1])
+    else:
+        for which in ('small', 'default'):
+            subprocess.run(
+                [sys.executable, __file__, which], check=True)
+        for file in sorted(GOLDEN.iterdir()):
+            print(file.name, file.stat().st_size, 'bytes')

@@ -1,0 +1,120 @@
+"""ctypes binding of `libpromonet_hip.so` (C ABI: include/promonet_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or a call
+is made with CPU tensors, this module raises.
+"""
+import ctypes
+import os
+from pathlib import Path
+
+import torch
+
+LIB_PATH = Path(__file__).parent / 'lib' / 'libpromonet_hip.so'
+
+PM_F32, PM_F16, PM_BF16 = 0, 1, 2
+DTYPES = {'fp32': PM_F32, 'f32': PM_F32, 'f16': PM_F16, 'fp16': PM_F16,
+          'bf16': PM_BF16}
+MAX_STAGES, MAX_RESBLOCKS, MAX_DILATIONS = 8, 4, 4
+
+c_float_p = ctypes.c_void_p
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+class HifiganConfig(ctypes.Structure):
+    _fields_ = [
+        ('num_features', ctypes.c_int),
+        ('global_channels', ctypes.c_int),
+        ('initial_channels', ctypes.c_int),
+        ('num_stages', ctypes.c_int),
+        ('upsample_rates', ctypes.c_int * MAX_STAGES),
+        ('upsample_kernel_sizes', ctypes.c_int * MAX_STAGES),
+        ('num_resblocks', ctypes.c_int),
+        ('resblock_kernel_sizes', ctypes.c_int * MAX_RESBLOCKS),
+        ('num_dilations', ctypes.c_int),
+        ('resblock_dilations', (ctypes.c_int * MAX_DILATIONS) * MAX_RESBLOCKS),
+        ('compute_dtype', ctypes.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/promonet_hip.h declares
+_I, _F, _P, _S = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+SIGNATURES = {
+    'pm_version': (_I, []),
+    'pm_last_error': (ctypes.c_char_p, []),
+    'pm_hifigan_create': (_I, [ctypes.POINTER(HifiganConfig),
+                               ctypes.POINTER(_P)]),
+    'pm_hifigan_destroy': (_I, [_P]),
+    'pm_hifigan_load_tensor': (_I, [_P, ctypes.c_char_p, _P, c_int64_p, _I, _P]),
+    'pm_hifigan_finalize': (_I, [_P, _P]),
+    'pm_hifigan_workspace_bytes': (_S, [_P, _I, _I]),
+    'pm_hifigan_hopsize': (_I, [_P]),
+    'pm_hifigan_features_cl_channels': (_I, [_P]),
+    'pm_hifigan_forward': (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _S, _P]),
+    'pm_hifigan_forward_cl': (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _S, _P]),
+    'pm_hifigan_profile_enable': (_I, [_P, _I]),
+    'pm_hifigan_profile_collect': (_I, [_P]),
+    'pm_hifigan_profile_reset': (_I, [_P]),
+    'pm_hifigan_profile_report': (ctypes.c_char_p, [_P]),
+    'pm_prepare_features': (_I, [_P] * 8 + [_I] * 8 + [_F] * 5 + [_P]),
+    'pm_prepare_global_features': (_I, [_P] * 5 + [_I, _I, _P]),
+    'pm_op_workspace_bytes': (_S, [_I, _I, _I]),
+    'pm_block_iteration_cl': (_I, [_I] + [_P] * 6 + [_I] * 6 + [_F, _P, _S, _P]),
+    'pm_conv_transpose_cl': (_I, [_I] + [_P] * 4 + [_I] * 6 + [_P, _S, _P]),
+    'pm_out_conv_tanh': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'pm_fold_weight_norm': (_I, [_P, _P, _P, _I, _I, _P]),
+    'pm_to_channels_last': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'pm_stft_scratch_bytes': (_S, [_I, _I]),
+    'pm_stft_magnitude': (_I, [_P, _P, _I, _I, _P, _S, _P]),
+    'pm_linear_to_mel': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    'pm_loudness_scratch_bytes': (_S, [_I, _I]),
+    'pm_loudness': (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _S, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it is missing."""
+    global _lib
+    if _lib is None:
+        path = Path(os.environ.get('PROMONET_HIP_LIB', LIB_PATH))
+        if not path.exists():
+            raise RuntimeError(
+                f'{path} not found: build it with `make -j4` (or '
+                '`python -c "import __graft_entry__ as g; g.build()"`). '
+                'promonet_amd has no CPU fallback.')
+        handle = ctypes.CDLL(str(path))
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        message = lib().pm_last_error().decode()
+        raise RuntimeError(f'libpromonet_hip error {code}: {message}')
+
+
+def ptr(tensor, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA/HIP tensor."""
+    if tensor is None:
+        return None
+    if not tensor.is_cuda:
+        raise RuntimeError(
+            'promonet_amd runs on an AMD GPU only (tensor is on '
+            f'{tensor.device}); there is no CPU fallback')
+    if tensor.dtype != dtype:
+        raise RuntimeError(f'expected {dtype}, got {tensor.dtype}')
+    if not tensor.is_contiguous():
+        raise RuntimeError('tensor must be contiguous')
+    return tensor.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def shape_array(shape):
+    return (ctypes.c_int64 * len(shape))(*shape)

@@ -1,0 +1,96 @@
+"""Import-time constants of the default configuration (`config/promonet.py`).
+
+Mirrors the values the reference freezes at import through yapecs
+(`promonet/config/defaults.py`, `promonet/config/static.py`); line numbers
+refer to those files. Only the constants the synthesis hot path and its
+preprocessing read are reproduced.
+"""
+import math
+from pathlib import Path
+
+CONFIG = 'promonet'
+
+# Audio parameters (defaults.py:24-52)
+DYNAMIC_RANGE_COMPRESSION_THRESHOLD = None
+FMIN = 50.
+FMAX = 550.
+HOPSIZE = 256
+MIN_DB = -100.
+NUM_MELS = 80
+NUM_FFT = 1024
+REF_DB = 20.
+SAMPLE_RATE = 22050
+WINDOW_SIZE = 1024
+
+# Data / feature parameters (defaults.py:60-135)
+AUGMENT_LOUDNESS = True
+AUGMENT_PITCH = True
+LOUDNESS_BANDS = 8
+PITCH_EMBEDDING = True
+PITCH_BINS = 256
+PITCH_EMBEDDING_SIZE = 64
+PPG_CHANNELS = 40
+SPARSE_PPG_METHOD = 'percentile'
+SPARSE_PPG_THRESHOLD = 0.85
+SPECTROGRAM_ONLY = False
+TRAINING_DATASET = 'vctk'
+VARIABLE_PITCH_BINS = True
+VITERBI_DECODE_PITCH = True
+INPUT_FEATURES = ['loudness', 'pitch', 'periodicity', 'ppg']
+
+# Model parameters (defaults.py:213-289)
+LRELU_SLOPE = .1
+MODEL = 'hifigan'
+HIFIGAN_RESBLOCK_KERNEL_SIZES = [3, 7, 11]
+HIFIGAN_RESBLOCK_DILATION_SIZES = [[1, 3, 5], [1, 3, 5], [1, 3, 5]]
+HIFIGAN_UPSAMPLE_INITIAL_SIZE = 512
+HIFIGAN_UPSAMPLE_KERNEL_SIZES = [16, 16, 4, 4]
+HIFIGAN_UPSAMPLE_RATES = [8, 8, 2, 2]
+SPEAKER_CHANNELS = 256
+ZERO_SHOT = False
+STEPS = 800000
+NUM_WORKERS = 10
+
+# MFMA operand type of the HIP engine: 'f16' (default; passes the 1e-4
+# parity gate at the bf16 MFMA rate), 'bf16', or 'fp32' (exact)
+COMPUTE_DTYPE = 'f16'
+
+ASSETS_DIR = Path(__file__).parent / 'assets'
+
+
+def derived():
+    """Constants of config/static.py, recomputed from the values above."""
+    g = globals()
+    g['LOG_DYNAMIC_RANGE_COMPRESSION_THRESHOLD'] = (
+        None if DYNAMIC_RANGE_COMPRESSION_THRESHOLD is None else
+        math.log(DYNAMIC_RANGE_COMPRESSION_THRESHOLD))          # static.py:12-14
+    g['LOG_FMIN'] = math.log2(FMIN)                             # static.py:17
+    g['LOG_FMAX'] = math.log2(FMAX)
+    g['GLOBAL_CHANNELS'] = (
+        SPEAKER_CHANNELS + AUGMENT_PITCH + AUGMENT_LOUDNESS)    # static.py:42-45
+    g['NUM_FEATURES'] = NUM_MELS if SPECTROGRAM_ONLY else (
+        PPG_CHANNELS +
+        ('loudness' in INPUT_FEATURES) * LOUDNESS_BANDS +
+        ('periodicity' in INPUT_FEATURES) +
+        ('pitch' in INPUT_FEATURES) * (
+            PITCH_EMBEDDING_SIZE if PITCH_EMBEDDING else 1))    # static.py:48-53
+    g['NUM_SPEAKERS'] = {
+        'daps': 20, 'libritts': 1230, 'vctk': 109}[TRAINING_DATASET]
+    g['NUM_PREVIOUS_SAMPLES'] = 1                               # static.py:69-74
+
+
+derived()
+
+
+def configure(**overrides):
+    """Override constants BEFORE constructing models (the reference does this
+    once, at import, from `--config` files: promonet/__init__.py:7-15)."""
+    import promonet_amd
+    for key, value in overrides.items():
+        if key not in globals():
+            raise ValueError(f'Unknown configuration parameter {key}')
+        globals()[key] = value
+    derived()
+    for key, value in globals().items():
+        if key.isupper():
+            setattr(promonet_amd, key, value)

@@ -1,0 +1,972 @@
+// C ABI of libpromonet_hip.so (see include/promonet_hip.h) and the HiFi-GAN
+// engine behind it: weight folding / packing at load, workspace planning and
+// the per-forward launch sequence. Host C++; every kernel it launches is
+// hand-written HIP for gfx950 (pm_conv.h, pm_misc.h, pm_stft.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/promonet_hip.h"
+#include "pm_launch.h"
+#include "pm_misc.h"
+#include "pm_stft.h"
+
+#define PM_VERSION 100
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_error[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess)                                                \
+            return fail(PM_EHIP, "%s failed: %s (%s:%d)", #expr,             \
+                        hipGetErrorString(e_), __FILE__, __LINE__);          \
+    } while (0)
+
+static inline int pad32(int c) { return (c + 31) / 32 * 32; }
+static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+static inline int esz(int dtype) { return dtype == PM_F32 ? 4 : 2; }
+
+// ---------------------------------------------------------------------------
+// dtype dispatch
+// ---------------------------------------------------------------------------
+static hipError_t launch_pair(
+    int dtype, int C, int K, const PairArgs& a, hipStream_t s) {
+    switch (dtype) {
+        case PM_F32: return pm_launch_pair<ElemF32>(C, K, a, s);
+        case PM_F16: return pm_launch_pair<ElemF16>(C, K, a, s);
+        case PM_BF16: return pm_launch_pair<ElemBF16>(C, K, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_single(
+    int dtype, int kind, int ch, int cfg, const SingleArgs& a, hipStream_t s) {
+    switch (dtype) {
+        case PM_F32: return pm_launch_single<ElemF32>(kind, ch, cfg, a, s);
+        case PM_F16: return pm_launch_single<ElemF16>(kind, ch, cfg, a, s);
+        case PM_BF16: return pm_launch_single<ElemBF16>(kind, ch, cfg, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_pack(int dtype, const PackArgs& a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.total + 255) / 256);
+    switch (dtype) {
+        case PM_F32:
+            hipLaunchKernelGGL(pm_pack_kernel<ElemF32>, dim3(grid), dim3(256), 0, s, a);
+            break;
+        case PM_F16:
+            hipLaunchKernelGGL(pm_pack_kernel<ElemF16>, dim3(grid), dim3(256), 0, s, a);
+            break;
+        case PM_BF16:
+            hipLaunchKernelGGL(pm_pack_kernel<ElemBF16>, dim3(grid), dim3(256), 0, s, a);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// Geometry of one packed convolution
+struct ConvGeom {
+    int mode = 0;            // 0 conv, 1 conv-transpose
+    int cout = 0, cin = 0, k = 0;
+    int cout_pad = 0, cin_pad = 0;
+    int M = 0;               // packed rows (cout_pad, or r * cout_pad)
+    int ch = 64, kt = 0;
+    int r = 0, p = 0;
+    size_t packed_elems() const { return (size_t)M * cin_pad * kt; }
+};
+
+static hipError_t pack_weights(
+    int dtype, const ConvGeom& g, const float* w, void* out, hipStream_t s) {
+    PackArgs a;
+    a.w = w; a.out = out; a.mode = g.mode;
+    a.cout = g.cout; a.cin = g.cin; a.k = g.k;
+    a.cout_pad = g.cout_pad; a.cin_pad = g.cin_pad;
+    a.mtiles = g.M / 32; a.nch = g.cin_pad / g.ch; a.ch = g.ch; a.kt = g.kt;
+    a.r = g.r; a.p = g.p;
+    a.total = (long long)g.packed_elems();
+    return launch_pack(dtype, a, s);
+}
+
+static hipError_t pad_bias(
+    const float* src, float* dst, int n, int n_pad, int rep, hipStream_t s) {
+    const int total = n_pad * rep;
+    hipLaunchKernelGGL(pm_pad_bias_kernel, dim3((total + 255) / 256),
+                       dim3(256), 0, s, src, dst, n, n_pad, rep);
+    return hipGetLastError();
+}
+
+static int single_cfg(int M, int ch, int wave64_ok) {
+    if (M % 256 == 0 && ch == 64 && wave64_ok) return 0;
+    if (M % 64 == 0) return 1;
+    return 2;
+}
+
+// ---------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------
+struct Layer {
+    ConvGeom geom;
+    void* w = nullptr;        // packed
+    float* bias = nullptr;    // padded (tiled per phase for conv-transpose)
+    float* tmp_g = nullptr;   // weight-norm pair awaiting its partner
+    float* tmp_v = nullptr;
+    bool has_w = false, has_b = false;
+    int cfg = 0;
+};
+
+struct Stage {
+    int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0, r = 0, k = 0;
+    Layer up;
+    Layer c1[PM_MAX_RESBLOCKS][PM_MAX_DILATIONS];
+    Layer c2[PM_MAX_RESBLOCKS][PM_MAX_DILATIONS];
+};
+
+struct pm_hifigan_s {
+    pm_hifigan_config cfg;
+    int dtype = PM_F16;
+    int cfp = 0, c0 = 0, c0p = 0, hop = 1;
+    Layer in_conv;
+    float* spk_w = nullptr; float* spk_b = nullptr;
+    bool has_spk_w = false, has_spk_b = false;
+    float* out_w = nullptr; bool has_out_w = false;
+    int c_last = 0, c_last_pad = 0;
+    std::vector<Stage> stages;
+    bool finalized = false;
+    // ---- optional per-launch timing with HIP events (bench.py roofline) ----
+    bool profile = false;
+    std::vector<hipEvent_t> events;      // pool, grown on demand
+    size_t events_used = 0;
+    struct Mark { std::string label; double flops, bytes; size_t e0, e1; };
+    std::vector<Mark> marks;             // launches since the last collect
+    struct Acc { long long count = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Acc> totals;
+    std::string report;
+};
+
+static int prof_event(pm_hifigan_t h, hipStream_t s, size_t* index) {
+    if (h->events_used == h->events.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->events.push_back(e);
+    }
+    *index = h->events_used++;
+    HIP_TRY(hipEventRecord(h->events[*index], s));
+    return PM_OK;
+}
+
+// Bracket the launch(es) issued by `body` with two events on the same stream
+#define PROF(h, s, label_, flops_, bytes_, body)                             \
+    do {                                                                     \
+        size_t e0_ = 0, e1_ = 0;                                             \
+        if ((h)->profile) { int r_ = prof_event(h, s, &e0_); if (r_) return r_; } \
+        body;                                                                \
+        if ((h)->profile) {                                                  \
+            int r_ = prof_event(h, s, &e1_); if (r_) return r_;              \
+            (h)->marks.push_back({label_, (double)(flops_), (double)(bytes_), e0_, e1_}); \
+        }                                                                    \
+    } while (0)
+
+static void free_layer(Layer& l) {
+    if (l.w) hipFree(l.w);
+    if (l.bias) hipFree(l.bias);
+    if (l.tmp_g) hipFree(l.tmp_g);
+    if (l.tmp_v) hipFree(l.tmp_v);
+    l = Layer();
+}
+
+extern "C" int pm_version(void) { return PM_VERSION; }
+extern "C" const char* pm_last_error(void) { return g_error; }
+
+extern "C" int pm_hifigan_create(
+    const pm_hifigan_config* c, pm_hifigan_t* out) {
+    if (!c || !out) return fail(PM_EINVAL, "null argument");
+    if (c->compute_dtype < 0 || c->compute_dtype > 2)
+        return fail(PM_EINVAL, "compute_dtype %d unknown", c->compute_dtype);
+    if (c->num_stages < 1 || c->num_stages > PM_MAX_STAGES ||
+        c->num_resblocks < 1 || c->num_resblocks > PM_MAX_RESBLOCKS ||
+        c->num_dilations < 1 || c->num_dilations > PM_MAX_DILATIONS)
+        return fail(PM_EINVAL, "stage / resblock / dilation count out of range");
+    if (c->num_features < 1 || c->global_channels < 1 ||
+        c->initial_channels < (1 << c->num_stages))
+        return fail(PM_EINVAL, "bad channel configuration");
+    for (int j = 0; j < c->num_resblocks; ++j) {
+        const int k = c->resblock_kernel_sizes[j];
+        if (k != 3 && k != 7 && k != 11)
+            return fail(PM_EINVAL,
+                        "resblock kernel size %d unsupported (3, 7, 11)", k);
+        for (int n = 0; n < c->num_dilations; ++n) {
+            const int d = c->resblock_dilations[j][n];
+            if (d < 1 || d > 5)
+                return fail(PM_EINVAL, "dilation %d unsupported (1..5)", d);
+        }
+    }
+    auto* h = new pm_hifigan_s();
+    h->cfg = *c;
+    h->dtype = c->compute_dtype;
+    h->cfp = pad32(c->num_features);
+    h->c0 = c->initial_channels;
+    h->c0p = pad32(h->c0);
+    h->hop = 1;
+    h->stages.resize(c->num_stages);
+    for (int i = 0; i < c->num_stages; ++i) {
+        Stage& s = h->stages[i];
+        s.r = c->upsample_rates[i];
+        s.k = c->upsample_kernel_sizes[i];
+        if (s.r < 2 || (s.r & 1) || s.k != 2 * s.r) {
+            delete h;
+            return fail(PM_EINVAL,
+                        "upsample stage %d: rate %d kernel %d unsupported "
+                        "(need even rate and kernel == 2 * rate)", i,
+                        c->upsample_rates[i], c->upsample_kernel_sizes[i]);
+        }
+        s.cin = h->c0 >> i;
+        s.cout = h->c0 >> (i + 1);
+        s.cin_pad = pad32(s.cin);
+        s.cout_pad = pad32(s.cout);
+        if (s.cout_pad != 32 && s.cout_pad != 64 && s.cout_pad != 128 &&
+            s.cout_pad != 256) {
+            delete h;
+            return fail(PM_EINVAL,
+                        "stage %d: %d channels unsupported (padded channel "
+                        "count must be 32, 64, 128 or 256)", i, s.cout);
+        }
+        h->hop *= s.r;
+        // conv-transpose as a polyphase GEMM
+        ConvGeom& g = s.up.geom;
+        g.mode = 1; g.cout = s.cout; g.cin = s.cin; g.k = s.k;
+        g.cout_pad = s.cout_pad; g.cin_pad = s.cin_pad;
+        g.M = s.r * s.cout_pad; g.kt = 2; g.r = s.r; g.p = s.r / 2;
+        g.ch = (s.cin_pad % 64 == 0) ? 64 : 32;
+        s.up.cfg = single_cfg(
+            g.M, g.ch, ((s.r / 2) * s.cout_pad) % 64 == 0);
+        for (int j = 0; j < c->num_resblocks; ++j)
+            for (int n = 0; n < c->num_dilations; ++n)
+                for (int which = 0; which < 2; ++which) {
+                    ConvGeom& q = (which ? s.c2 : s.c1)[j][n].geom;
+                    q.mode = 0; q.cout = q.cin = s.cout;
+                    q.k = c->resblock_kernel_sizes[j];
+                    q.cout_pad = q.cin_pad = q.M = s.cout_pad;
+                    q.kt = q.k;
+                    q.ch = s.cout_pad < 64 ? s.cout_pad : 64;
+                }
+    }
+    {
+        ConvGeom& g = h->in_conv.geom;
+        g.mode = 0; g.cout = h->c0; g.cin = c->num_features; g.k = 7;
+        g.cout_pad = g.M = h->c0p; g.cin_pad = h->cfp; g.kt = 7;
+        g.ch = (h->cfp % 64 == 0) ? 64 : 32;
+        h->in_conv.cfg = single_cfg(g.M, g.ch, 1);
+    }
+    h->c_last = h->stages.back().cout;
+    h->c_last_pad = h->stages.back().cout_pad;
+    if (h->c_last_pad > 64) {
+        delete h;
+        return fail(PM_EINVAL, "output conv supports <= 64 input channels");
+    }
+    *out = h;
+    return PM_OK;
+}
+
+extern "C" int pm_hifigan_destroy(pm_hifigan_t h) {
+    if (!h) return PM_OK;
+    free_layer(h->in_conv);
+    if (h->spk_w) hipFree(h->spk_w);
+    if (h->spk_b) hipFree(h->spk_b);
+    if (h->out_w) hipFree(h->out_w);
+    for (auto e : h->events) hipEventDestroy(e);
+    for (auto& s : h->stages) {
+        free_layer(s.up);
+        for (int j = 0; j < PM_MAX_RESBLOCKS; ++j)
+            for (int n = 0; n < PM_MAX_DILATIONS; ++n) {
+                free_layer(s.c1[j][n]);
+                free_layer(s.c2[j][n]);
+            }
+    }
+    delete h;
+    return PM_OK;
+}
+
+static size_t numel(const int64_t* shape, int ndim) {
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    return n;
+}
+
+static int copy_dev(float** dst, const float* src, size_t n, hipStream_t s) {
+    if (!*dst) HIP_TRY(hipMalloc((void**)dst, n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(float),
+                           hipMemcpyDeviceToDevice, s));
+    return PM_OK;
+}
+
+// Pack a folded torch-layout weight into the layer
+static int set_weight(
+    pm_hifigan_t h, Layer& l, const float* w, const int64_t* shape, int ndim,
+    hipStream_t s, const char* name) {
+    const ConvGeom& g = l.geom;
+    const int64_t d0 = g.mode == 0 ? g.cout : g.cin;
+    const int64_t d1 = g.mode == 0 ? g.cin : g.cout;
+    if (ndim != 3 || shape[0] != d0 || shape[1] != d1 || shape[2] != g.k)
+        return fail(PM_EINVAL, "%s: expected shape (%lld, %lld, %d)", name,
+                    (long long)d0, (long long)d1, g.k);
+    const size_t bytes = g.packed_elems() * esz(h->dtype);
+    if (!l.w) HIP_TRY(hipMalloc(&l.w, bytes));
+    HIP_TRY(pack_weights(h->dtype, g, w, l.w, s));
+    l.has_w = true;
+    return PM_OK;
+}
+
+static int set_bias(
+    Layer& l, const float* b, const int64_t* shape, int ndim, hipStream_t s,
+    const char* name) {
+    const ConvGeom& g = l.geom;
+    if (ndim != 1 || shape[0] != g.cout)
+        return fail(PM_EINVAL, "%s: expected shape (%d)", name, g.cout);
+    const int rep = g.mode == 1 ? g.r : 1;
+    if (!l.bias)
+        HIP_TRY(hipMalloc((void**)&l.bias,
+                          (size_t)g.cout_pad * rep * sizeof(float)));
+    HIP_TRY(pad_bias(b, l.bias, g.cout, g.cout_pad, rep, s));
+    l.has_b = true;
+    return PM_OK;
+}
+
+static int set_norm_part(
+    pm_hifigan_t h, Layer& l, bool is_g, const float* t, const int64_t* shape,
+    int ndim, hipStream_t s, const char* name) {
+    const ConvGeom& g = l.geom;
+    const int64_t rows = g.mode == 0 ? g.cout : g.cin;
+    const int64_t cols = (g.mode == 0 ? g.cin : g.cout) * (int64_t)g.k;
+    if (is_g) {
+        if (ndim != 3 || shape[0] != rows || shape[1] != 1 || shape[2] != 1)
+            return fail(PM_EINVAL, "%s: expected shape (%lld, 1, 1)", name,
+                        (long long)rows);
+        int rc = copy_dev(&l.tmp_g, t, rows, s);
+        if (rc) return rc;
+    } else {
+        if (ndim != 3 || (int64_t)numel(shape, ndim) != rows * cols ||
+            shape[0] != rows)
+            return fail(PM_EINVAL, "%s: unexpected weight_v shape", name);
+        int rc = copy_dev(&l.tmp_v, t, rows * cols, s);
+        if (rc) return rc;
+    }
+    if (l.tmp_g && l.tmp_v) {
+        float* folded = nullptr;
+        HIP_TRY(hipMalloc((void**)&folded, rows * cols * sizeof(float)));
+        hipLaunchKernelGGL(pm_fold_kernel, dim3((unsigned)rows), dim3(256), 0,
+                           s, l.tmp_g, l.tmp_v, folded, (int)cols);
+        HIP_TRY(hipGetLastError());
+        const int64_t wshape[3] = {
+            rows, g.mode == 0 ? (int64_t)g.cin : (int64_t)g.cout, g.k};
+        int rc = set_weight(h, l, folded, wshape, 3, s, name);
+        HIP_TRY(hipStreamSynchronize(s));
+        hipFree(folded);
+        hipFree(l.tmp_g); hipFree(l.tmp_v);
+        l.tmp_g = l.tmp_v = nullptr;
+        if (rc) return rc;
+    }
+    return PM_OK;
+}
+
+static int set_layer_tensor(
+    pm_hifigan_t h, Layer& l, const char* leaf, const float* t,
+    const int64_t* shape, int ndim, hipStream_t s, const char* name) {
+    if (!strcmp(leaf, "weight")) return set_weight(h, l, t, shape, ndim, s, name);
+    if (!strcmp(leaf, "bias")) return set_bias(l, t, shape, ndim, s, name);
+    if (!strcmp(leaf, "weight_g"))
+        return set_norm_part(h, l, true, t, shape, ndim, s, name);
+    if (!strcmp(leaf, "weight_v"))
+        return set_norm_part(h, l, false, t, shape, ndim, s, name);
+    return fail(PM_EINVAL, "%s: unknown tensor", name);
+}
+
+extern "C" int pm_hifigan_load_tensor(
+    pm_hifigan_t h, const char* name, const float* dev, const int64_t* shape,
+    int ndim, void* stream) {
+    if (!h || !name || !dev || !shape) return fail(PM_EINVAL, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = (int)h->stages.size();
+    int rc = PM_EINVAL;
+    int i = 0, j = 0, n = 0, which = 0;
+    char leaf[32] = "";
+    if (!strncmp(name, "input_feature_conv.", 19)) {
+        rc = set_layer_tensor(h, h->in_conv, name + 19, dev, shape, ndim, s, name);
+    } else if (!strcmp(name, "input_speaker_conv.weight")) {
+        if (ndim != 3 || shape[0] != h->c0 ||
+            shape[1] != h->cfg.global_channels || shape[2] != 1)
+            return fail(PM_EINVAL, "%s: unexpected shape", name);
+        rc = copy_dev(&h->spk_w, dev, numel(shape, ndim), s);
+        h->has_spk_w = rc == PM_OK;
+    } else if (!strcmp(name, "input_speaker_conv.bias")) {
+        if (ndim != 1 || shape[0] != h->c0)
+            return fail(PM_EINVAL, "%s: unexpected shape", name);
+        rc = copy_dev(&h->spk_b, dev, numel(shape, ndim), s);
+        h->has_spk_b = rc == PM_OK;
+    } else if (sscanf(name, "model.%d.model.2.model.%d.convs%d.%d.%31s", &i,
+                      &j, &which, &n, leaf) == 5) {
+        if (i < 0 || i >= ns || j < 0 || j >= h->cfg.num_resblocks || n < 0 ||
+            n >= h->cfg.num_dilations || which < 1 || which > 2)
+            return fail(PM_EINVAL, "%s: index out of range", name);
+        Layer& l = (which == 1 ? h->stages[i].c1 : h->stages[i].c2)[j][n];
+        rc = set_layer_tensor(h, l, leaf, dev, shape, ndim, s, name);
+    } else if (sscanf(name, "model.%d.model.1.%31s", &i, leaf) == 2) {
+        if (i < 0 || i >= ns)
+            return fail(PM_EINVAL, "%s: stage out of range", name);
+        rc = set_layer_tensor(h, h->stages[i].up, leaf, dev, shape, ndim, s, name);
+    } else if (sscanf(name, "model.%d.%31s", &i, leaf) == 2 && i == ns + 1 &&
+               !strcmp(leaf, "weight")) {
+        if (ndim != 3 || shape[0] != 1 || shape[1] != h->c_last ||
+            shape[2] != 7)
+            return fail(PM_EINVAL, "%s: expected shape (1, %d, 7)", name,
+                        h->c_last);
+        rc = copy_dev(&h->out_w, dev, numel(shape, ndim), s);
+        h->has_out_w = rc == PM_OK;
+    } else {
+        return fail(PM_EINVAL, "%s: not a HiFiGAN state-dict key", name);
+    }
+    if (rc != PM_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    h->finalized = false;
+    return PM_OK;
+}
+
+extern "C" int pm_hifigan_finalize(pm_hifigan_t h, void* stream) {
+    if (!h) return fail(PM_EINVAL, "null handle");
+    auto check = [](const Layer& l, const std::string& what) -> int {
+        if (!l.has_w) return fail(PM_ESTATE, "missing tensor: %s weight", what.c_str());
+        if (!l.has_b) return fail(PM_ESTATE, "missing tensor: %s bias", what.c_str());
+        return PM_OK;
+    };
+    int rc;
+    if ((rc = check(h->in_conv, "input_feature_conv"))) return rc;
+    if (!h->has_spk_w || !h->has_spk_b)
+        return fail(PM_ESTATE, "missing tensor: input_speaker_conv");
+    if (!h->has_out_w) return fail(PM_ESTATE, "missing tensor: output conv");
+    for (size_t i = 0; i < h->stages.size(); ++i) {
+        Stage& s = h->stages[i];
+        if ((rc = check(s.up, "model." + std::to_string(i) + ".model.1")))
+            return rc;
+        for (int j = 0; j < h->cfg.num_resblocks; ++j)
+            for (int n = 0; n < h->cfg.num_dilations; ++n) {
+                const std::string base = "model." + std::to_string(i) +
+                    ".model.2.model." + std::to_string(j);
+                if ((rc = check(s.c1[j][n], base + ".convs1." + std::to_string(n))))
+                    return rc;
+                if ((rc = check(s.c2[j][n], base + ".convs2." + std::to_string(n))))
+                    return rc;
+            }
+    }
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    h->finalized = true;
+    return PM_OK;
+}
+
+extern "C" int pm_hifigan_hopsize(pm_hifigan_t h) { return h ? h->hop : 0; }
+extern "C" int pm_hifigan_features_cl_channels(pm_hifigan_t h) {
+    return h ? h->cfp : 0;
+}
+
+struct Plan {
+    size_t off_feat, off_gbias, off_buf, buf_elems, total;
+};
+
+static Plan make_plan(pm_hifigan_t h, int B, int T) {
+    Plan p;
+    size_t mx = (size_t)T * h->c0p;
+    size_t L = T;
+    for (auto& s : h->stages) {
+        L *= s.r;
+        mx = std::max(mx, L * (size_t)s.cout_pad);
+    }
+    p.buf_elems = align256((size_t)B * mx * sizeof(float)) / sizeof(float);
+    p.off_feat = 0;
+    p.off_gbias = align256((size_t)B * T * h->cfp * sizeof(float));
+    p.off_buf = p.off_gbias + align256((size_t)B * h->c0p * sizeof(float));
+    p.total = p.off_buf + 4 * p.buf_elems * sizeof(float);
+    return p;
+}
+
+extern "C" size_t pm_hifigan_workspace_bytes(pm_hifigan_t h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    return make_plan(h, B, T).total;
+}
+
+static int forward_impl(
+    pm_hifigan_t h, const float* features, bool features_cl, const float* g,
+    int gbatch, float* out, int B, int T, void* ws, size_t ws_bytes,
+    hipStream_t s) {
+    if (!h || !features || !g || !out || !ws)
+        return fail(PM_EINVAL, "null argument");
+    if (!h->finalized) return fail(PM_ESTATE, "pm_hifigan_finalize not called");
+    if (B < 1 || T < 1) return fail(PM_EINVAL, "empty batch or sequence");
+    if (gbatch != 1 && gbatch != B)
+        return fail(PM_EINVAL, "global_batch must be 1 or batch");
+    const Plan p = make_plan(h, B, T);
+    if (ws_bytes < p.total)
+        return fail(PM_ENOMEM, "workspace %zu < required %zu", ws_bytes, p.total);
+    char* base = (char*)ws;
+    float* feat = (float*)(base + p.off_feat);
+    float* gbias = (float*)(base + p.off_gbias);
+    float* buf[4];
+    for (int i = 0; i < 4; ++i)
+        buf[i] = (float*)(base + p.off_buf) + (size_t)i * p.buf_elems;
+
+    const float* feat_cl = features;
+    if (!features_cl) {
+        dim3 grid((T + 31) / 32, h->cfp / 32, B);
+        PROF(h, s, "to_channels_last", 0,
+             (double)B * T * (h->cfg.num_features + h->cfp) * 4, {
+            hipLaunchKernelGGL(pm_to_channels_last_kernel, grid, dim3(256), 0,
+                               s, features, feat, h->cfg.num_features, T,
+                               h->cfp);
+            HIP_TRY(hipGetLastError());
+        });
+        feat_cl = feat;
+    }
+    // speaker conditioning as a per-utterance bias of the input conv
+    hipLaunchKernelGGL(pm_speaker_bias_kernel, dim3((h->c0p + 3) / 4, gbatch),
+                       dim3(256), 0, s, g, h->spk_w, h->spk_b, gbias,
+                       h->cfg.global_channels, h->c0, h->c0p);
+    HIP_TRY(hipGetLastError());
+    {
+        SingleArgs a = {};
+        a.x = feat_cl; a.out = buf[0]; a.w = h->in_conv.w;
+        a.bias = h->in_conv.bias; a.gbias = gbias; a.gbias_batch = gbatch;
+        a.B = B; a.L = T; a.Lout = T; a.Cin = h->cfp; a.M = h->c0p;
+        a.lrelu = 0; a.pad = 3; a.phase_r = 0; a.phase_c = 1;
+        PROF(h, s, "input_conv",
+             2.0 * h->c0 * h->cfg.num_features * 7 * B * T,
+             (double)B * T * (h->cfg.num_features + h->c0) * 4, {
+            HIP_TRY(launch_single(h->dtype, 0, h->in_conv.geom.ch,
+                                  h->in_conv.cfg, a, s));
+        });
+    }
+    int xi = 0;        // index of the buffer holding the stage input
+    int L = T;
+    const float scale = 1.f / (float)h->cfg.num_resblocks;
+    for (auto& st : h->stages) {
+        const int ui = (xi + 1) & 3, ai = (xi + 2) & 3, bi = (xi + 3) & 3;
+        {
+            SingleArgs a = {};
+            a.x = buf[xi]; a.out = buf[ui]; a.w = st.up.w; a.bias = st.up.bias;
+            a.gbias = nullptr; a.gbias_batch = 1;
+            a.B = B; a.L = L; a.Lout = L; a.Cin = st.cin_pad;
+            a.M = st.up.geom.M; a.lrelu = 1; a.pad = 1;
+            a.phase_c = st.cout_pad; a.phase_p = st.r / 2; a.phase_r = st.r;
+            char label[64];
+            snprintf(label, sizeof(label), "convT_c%d_r%d", st.cin, st.r);
+            PROF(h, s, label, 2.0 * st.cin * st.cout * st.k * B * L,
+                 (double)B * L * (st.cin + (double)st.r * st.cout) * 4, {
+                HIP_TRY(launch_single(h->dtype, 1, st.up.geom.ch, st.up.cfg,
+                                      a, s));
+            });
+        }
+        L *= st.r;
+        const int si = xi;   // stage input is dead after the upsampler
+        for (int j = 0; j < h->cfg.num_resblocks; ++j) {
+            const float* src = buf[ui];
+            for (int n = 0; n < h->cfg.num_dilations; ++n) {
+                const bool last = n == h->cfg.num_dilations - 1;
+                float* dst = last ? buf[si] : ((n & 1) ? buf[bi] : buf[ai]);
+                PairArgs a = {};
+                a.x = src; a.out = dst;
+                a.w1 = st.c1[j][n].w; a.b1 = st.c1[j][n].bias;
+                a.w2 = st.c2[j][n].w; a.b2 = st.c2[j][n].bias;
+                a.B = B; a.L = L;
+                a.dilation = h->cfg.resblock_dilations[j][n];
+                a.mode = last ? (j == 0 ? 1 : 2) : 0;
+                a.scale = scale;
+                const int K = h->cfg.resblock_kernel_sizes[j];
+                char label[64];
+                snprintf(label, sizeof(label), "pair_c%d_k%d", st.cout, K);
+                PROF(h, s, label, 4.0 * st.cout * st.cout * K * B * L,
+                     (double)B * L * st.cout * 4 * (a.mode == 2 ? 3 : 2), {
+                    HIP_TRY(launch_pair(h->dtype, st.cout_pad, K, a, s));
+                });
+                src = dst;
+            }
+        }
+        xi = si;
+    }
+    {
+        constexpr int TH = 256;
+        const int C = h->c_last_pad;
+        const size_t smem = ((size_t)(TH + 6) * (C + 1) + 7 * C) * sizeof(float);
+        PROF(h, s, "out_conv_tanh", 2.0 * h->c_last * 7 * B * L,
+             (double)B * L * (h->c_last + 1) * 4, {
+            hipLaunchKernelGGL(pm_out_conv_kernel<TH>,
+                               dim3((L + TH - 1) / TH, B), dim3(TH), smem, s,
+                               buf[xi], h->out_w, out, L, C, h->c_last);
+            HIP_TRY(hipGetLastError());
+        });
+    }
+    return PM_OK;
+}
+
+// ---- profiling API ---------------------------------------------------------
+extern "C" int pm_hifigan_profile_enable(pm_hifigan_t h, int enable) {
+    if (!h) return fail(PM_EINVAL, "null handle");
+    h->profile = enable != 0;
+    return PM_OK;
+}
+
+// Synchronise, fold the event pairs recorded since the last call into the
+// per-label totals and recycle the events. Call between forwards at will.
+extern "C" int pm_hifigan_profile_collect(pm_hifigan_t h) {
+    if (!h) return fail(PM_EINVAL, "null handle");
+    for (auto& m : h->marks) {
+        HIP_TRY(hipEventSynchronize(h->events[m.e1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->events[m.e0], h->events[m.e1]));
+        auto& acc = h->totals[m.label];
+        acc.count += 1; acc.ms += ms; acc.flops += m.flops; acc.bytes += m.bytes;
+    }
+    h->marks.clear();
+    h->events_used = 0;
+    return PM_OK;
+}
+
+extern "C" int pm_hifigan_profile_reset(pm_hifigan_t h) {
+    if (!h) return fail(PM_EINVAL, "null handle");
+    int rc = pm_hifigan_profile_collect(h);
+    h->totals.clear();
+    return rc;
+}
+
+// Text report, one line per kernel label:
+//   label launches total_ms algorithmic_flops algorithmic_bytes
+extern "C" const char* pm_hifigan_profile_report(pm_hifigan_t h) {
+    if (!h) return "";
+    h->report.clear();
+    char line[256];
+    for (auto& kv : h->totals) {
+        snprintf(line, sizeof(line), "%s %lld %.6f %.6e %.6e\n",
+                 kv.first.c_str(), kv.second.count, kv.second.ms,
+                 kv.second.flops, kv.second.bytes);
+        h->report += line;
+    }
+    return h->report.c_str();
+}
+
+extern "C" int pm_hifigan_forward(
+    pm_hifigan_t h, const float* features, const float* g, int gbatch,
+    float* out, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    return forward_impl(h, features, false, g, gbatch, out, B, T, ws, ws_bytes,
+                        (hipStream_t)stream);
+}
+
+extern "C" int pm_hifigan_forward_cl(
+    pm_hifigan_t h, const float* features_cl, const float* g, int gbatch,
+    float* out, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    return forward_impl(h, features_cl, true, g, gbatch, out, B, T, ws,
+                        ws_bytes, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// conditioning
+// ---------------------------------------------------------------------------
+extern "C" int pm_prepare_features(
+    const float* loudness, const float* pitch, const float* periodicity,
+    const float* ppg, const float* pitch_edges, const float* pitch_table,
+    float* out_ref, float* out_cl, int B, int T, int F, int P, int NB, int E,
+    int bands, int cl_channels, float ppg_threshold, float fmin, float fmax,
+    float min_db, float ref_db, void* stream) {
+    if (!loudness || !pitch || !periodicity || !ppg || !pitch_edges ||
+        !pitch_table || (!out_ref && !out_cl))
+        return fail(PM_EINVAL, "null argument");
+    if (B < 1 || T < 1 || P < 2 || bands < 1 || bands > 16 || F < bands)
+        return fail(PM_EINVAL, "bad feature dimensions");
+    const int C = P + E + bands + 1;
+    if (out_cl && cl_channels < C)
+        return fail(PM_EINVAL, "cl_channels %d < %d", cl_channels, C);
+    FeatureArgs a;
+    a.loudness = loudness; a.pitch = pitch; a.periodicity = periodicity;
+    a.ppg = ppg; a.pitch_edges = pitch_edges; a.pitch_table = pitch_table;
+    a.out_cl = out_cl; a.out_ref = out_ref;
+    a.B = B; a.T = T; a.F = F; a.P = P; a.NB = NB; a.E = E; a.bands = bands;
+    a.Cpad = cl_channels;
+    const double step = (double)F / (double)bands;   // generator.py:174
+    for (int b = 0; b <= bands; ++b) a.band_start[b] = (int)(b * step);
+    // torch.quantile(..., interpolation='linear') in the tensor's dtype
+    const float rank = ppg_threshold * (float)(P - 1);
+    a.rank_below = (int)floorf(rank);
+    a.rank_above = (int)ceilf(rank);
+    a.rank_weight = rank - floorf(rank);
+    a.fmin = fmin; a.fmax = fmax; a.min_db = min_db;
+    a.db_range = ref_db - min_db;
+    constexpr int TH = 128;
+    hipLaunchKernelGGL(pm_prepare_features_kernel<TH>,
+                       dim3((T + TH - 1) / TH, B), dim3(TH),
+                       (size_t)P * TH * sizeof(float), (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" int pm_prepare_global_features(
+    const int64_t* speakers, const float* sbr, const float* lr,
+    const float* table, float* out, int B, int S, void* stream) {
+    if (!speakers || !sbr || !lr || !table || !out)
+        return fail(PM_EINVAL, "null argument");
+    hipLaunchKernelGGL(pm_global_features_kernel, dim3(B), dim3(256), 0,
+                       (hipStream_t)stream, (const long long*)speakers, sbr,
+                       lr, table, out, B, S);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-kernel entry points
+// ---------------------------------------------------------------------------
+extern "C" size_t pm_op_workspace_bytes(int c_in, int c_out, int k) {
+    const size_t ci = pad32(c_in), co = pad32(c_out);
+    return 2 * align256(ci * co * (size_t)k * 4) + 2 * align256(co * 64 * 4);
+}
+
+extern "C" int pm_block_iteration_cl(
+    int dtype, const float* x, float* out, const float* w1, const float* b1,
+    const float* w2, const float* b2, int B, int L, int C, int K, int d,
+    int mode, float scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !out || !w1 || !b1 || !w2 || !b2 || !ws)
+        return fail(PM_EINVAL, "null argument");
+    const int Cp = pad32(C);
+    if (Cp != 32 && Cp != 64 && Cp != 128 && Cp != 256)
+        return fail(PM_EINVAL, "channels %d unsupported", C);
+    if ((K != 3 && K != 7 && K != 11) || d < 1 || d > 5)
+        return fail(PM_EINVAL, "kernel %d / dilation %d unsupported", K, d);
+    if (ws_bytes < pm_op_workspace_bytes(C, C, K))
+        return fail(PM_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ConvGeom g;
+    g.mode = 0; g.cout = g.cin = C; g.k = K; g.cout_pad = g.cin_pad = g.M = Cp;
+    g.kt = K; g.ch = Cp < 64 ? Cp : 64;
+    char* base = (char*)ws;
+    const size_t wsz = align256((size_t)Cp * Cp * K * 4);
+    void* p1 = base; void* p2 = base + wsz;
+    float* pb1 = (float*)(base + 2 * wsz);
+    float* pb2 = pb1 + align256(Cp * 64 * 4) / 4;
+    HIP_TRY(pack_weights(dtype, g, w1, p1, s));
+    HIP_TRY(pack_weights(dtype, g, w2, p2, s));
+    HIP_TRY(pad_bias(b1, pb1, C, Cp, 1, s));
+    HIP_TRY(pad_bias(b2, pb2, C, Cp, 1, s));
+    PairArgs a = {};
+    a.x = x; a.out = out; a.w1 = p1; a.w2 = p2; a.b1 = pb1; a.b2 = pb2;
+    a.B = B; a.L = L; a.dilation = d; a.mode = mode; a.scale = scale;
+    HIP_TRY(launch_pair(dtype, Cp, K, a, s));
+    return PM_OK;
+}
+
+extern "C" int pm_conv_transpose_cl(
+    int dtype, const float* x, float* out, const float* w, const float* bias,
+    int B, int L, int c_in, int c_out, int r, int lrelu, void* ws,
+    size_t ws_bytes, void* stream) {
+    if (!x || !out || !w || !bias || !ws) return fail(PM_EINVAL, "null argument");
+    if (r < 2 || (r & 1)) return fail(PM_EINVAL, "rate %d unsupported", r);
+    if (ws_bytes < pm_op_workspace_bytes(c_in, c_out, 2 * r))
+        return fail(PM_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ConvGeom g;
+    g.mode = 1; g.cout = c_out; g.cin = c_in; g.k = 2 * r;
+    g.cout_pad = pad32(c_out); g.cin_pad = pad32(c_in);
+    g.M = r * g.cout_pad; g.kt = 2; g.r = r; g.p = r / 2;
+    g.ch = (g.cin_pad % 64 == 0) ? 64 : 32;
+    const int cfg = single_cfg(g.M, g.ch, ((r / 2) * g.cout_pad) % 64 == 0);
+    char* base = (char*)ws;
+    const size_t wsz = 2 * align256((size_t)g.cin_pad * g.cout_pad * g.k * 4);
+    float* pb = (float*)(base + wsz);
+    HIP_TRY(pack_weights(dtype, g, w, base, s));
+    HIP_TRY(pad_bias(bias, pb, c_out, g.cout_pad, r, s));
+    SingleArgs a = {};
+    a.x = x; a.out = out; a.w = base; a.bias = pb; a.gbias = nullptr;
+    a.gbias_batch = 1; a.B = B; a.L = L; a.Lout = L; a.Cin = g.cin_pad;
+    a.M = g.M; a.lrelu = lrelu; a.pad = 1;
+    a.phase_c = g.cout_pad; a.phase_p = r / 2; a.phase_r = r;
+    HIP_TRY(launch_single(dtype, 1, g.ch, cfg, a, s));
+    return PM_OK;
+}
+
+extern "C" int pm_out_conv_tanh(
+    const float* x, const float* w, float* out, int B, int L, int C,
+    void* stream) {
+    if (!x || !w || !out) return fail(PM_EINVAL, "null argument");
+    const int Cp = pad32(C);
+    if (Cp > 64) return fail(PM_EINVAL, "channels %d unsupported", C);
+    constexpr int TH = 256;
+    const size_t smem = ((size_t)(TH + 6) * (Cp + 1) + 7 * Cp) * sizeof(float);
+    hipLaunchKernelGGL(pm_out_conv_kernel<TH>, dim3((L + TH - 1) / TH, B),
+                       dim3(TH), smem, (hipStream_t)stream, x, w, out, L, Cp, C);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" int pm_fold_weight_norm(
+    const float* g, const float* v, float* w, int rows, int cols,
+    void* stream) {
+    if (!g || !v || !w || rows < 1 || cols < 1)
+        return fail(PM_EINVAL, "bad argument");
+    hipLaunchKernelGGL(pm_fold_kernel, dim3(rows), dim3(256), 0,
+                       (hipStream_t)stream, g, v, w, cols);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" int pm_to_channels_last(
+    const float* src, float* dst, int B, int C, int T, int c_pad,
+    void* stream) {
+    if (!src || !dst || c_pad % 32) return fail(PM_EINVAL, "bad argument");
+    dim3 grid((T + 31) / 32, c_pad / 32, B);
+    hipLaunchKernelGGL(pm_to_channels_last_kernel, grid, dim3(256), 0,
+                       (hipStream_t)stream, src, dst, C, T, c_pad);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// preprocessing
+// ---------------------------------------------------------------------------
+static const int NFFT = 1024, HOP = 256, BINS = 513, DFT_M = 1088;
+
+static std::mutex g_basis_mutex;
+static std::map<int, void*> g_basis;   // per device: packed windowed DFT basis
+
+static int get_dft_basis(void** out, hipStream_t s) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_basis_mutex);
+    auto it = g_basis.find(dev);
+    if (it != g_basis.end()) { *out = it->second; return PM_OK; }
+    float* raw = nullptr;
+    void* packed = nullptr;
+    const size_t raw_elems = 2ull * BINS * NFFT;
+    HIP_TRY(hipMalloc((void**)&raw, raw_elems * sizeof(float)));
+    HIP_TRY(hipMalloc(&packed, (size_t)DFT_M * NFFT * sizeof(float)));
+    hipLaunchKernelGGL(pm_dft_basis_kernel,
+                       dim3((unsigned)((raw_elems + 255) / 256)), dim3(256), 0,
+                       s, raw, BINS, NFFT, HOP);
+    HIP_TRY(hipGetLastError());
+    ConvGeom g;
+    g.mode = 0; g.cout = 2 * BINS; g.cin = HOP; g.k = NFFT / HOP;
+    g.cout_pad = g.M = DFT_M; g.cin_pad = HOP; g.kt = g.k; g.ch = 64;
+    HIP_TRY(pack_weights(PM_F32, g, raw, packed, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(raw);
+    g_basis[dev] = packed;
+    *out = packed;
+    return PM_OK;
+}
+
+extern "C" size_t pm_stft_scratch_bytes(int B, int N) {
+    if (B < 1 || N < HOP) return 0;
+    const size_t T = N / HOP;
+    return align256((size_t)B * (T + 3) * HOP * sizeof(float));
+}
+
+static int stft_launch(
+    int epi, const float* audio, float* out, unsigned* maxbits, int B, int N,
+    void* scratch, size_t scratch_bytes, hipStream_t s) {
+    if (!audio || !out || !scratch) return fail(PM_EINVAL, "null argument");
+    const int pad = (NFFT - HOP) / 2;
+    if (B < 1 || N <= pad)
+        return fail(PM_EINVAL, "need more than %d samples (reflect pad)", pad);
+    const int T = N / HOP;
+    if (T < 1) return fail(PM_EINVAL, "fewer samples than one hop");
+    if (scratch_bytes < pm_stft_scratch_bytes(B, N))
+        return fail(PM_ENOMEM, "scratch too small");
+    void* basis = nullptr;
+    int rc = get_dft_basis(&basis, s);
+    if (rc) return rc;
+    float* padded = (float*)scratch;
+    // only the first (T + 3) * HOP padded samples are ever framed
+    const int Np = (T + 3) * HOP;
+    hipLaunchKernelGGL(pm_reflect_pad_kernel, dim3((Np + 255) / 256, B),
+                       dim3(256), 0, s, audio, padded, N, pad, Np);
+    HIP_TRY(hipGetLastError());
+    SingleArgs a = {};
+    a.x = padded; a.out = out; a.w = basis; a.bias = nullptr;
+    a.gbias = nullptr; a.gbias_batch = 1;
+    a.B = B; a.L = T + 3; a.Lout = T; a.Cin = HOP; a.M = DFT_M;
+    a.bins = BINS; a.maxbits = maxbits; a.lrelu = 0; a.pad = 0;
+    a.phase_r = 0; a.phase_c = 1;
+    HIP_TRY(pm_launch_stft(epi, a, s));
+    return PM_OK;
+}
+
+extern "C" int pm_stft_magnitude(
+    const float* audio, float* out, int B, int N, void* scratch,
+    size_t scratch_bytes, void* stream) {
+    return stft_launch(1, audio, out, nullptr, B, N, scratch, scratch_bytes,
+                       (hipStream_t)stream);
+}
+
+extern "C" int pm_linear_to_mel(
+    const float* spec, const float* basis, float* out, int B, int F, int M,
+    int T, int use_threshold, float log_threshold, void* stream) {
+    if (!spec || !basis || !out) return fail(PM_EINVAL, "null argument");
+    hipLaunchKernelGGL(pm_mel_kernel, dim3((T + 255) / 256, M, B), dim3(256),
+                       0, (hipStream_t)stream, spec, basis, out, F, M, T,
+                       use_threshold, log_threshold);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" size_t pm_loudness_scratch_bytes(int B, int N) {
+    if (B < 1 || N < HOP) return 0;
+    const size_t T = N / HOP;
+    return pm_stft_scratch_bytes(B, N) +
+           align256((size_t)B * BINS * T * sizeof(float)) + align256(B * 4);
+}
+
+extern "C" int pm_loudness(
+    const float* audio, const float* a_weights, float* out, int B, int N,
+    int bands, float min_db, void* scratch, size_t scratch_bytes,
+    void* stream) {
+    if (!audio || !a_weights || !out || !scratch)
+        return fail(PM_EINVAL, "null argument");
+    if (bands < 1 || (bands > 16 && bands != BINS))
+        return fail(PM_EINVAL, "bands must be 1..16 or 513 (no averaging)");
+    if (scratch_bytes < pm_loudness_scratch_bytes(B, N) || N < HOP)
+        return fail(PM_ENOMEM, "scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = N / HOP;
+    char* base = (char*)scratch;
+    const size_t stft_bytes = pm_stft_scratch_bytes(B, N);
+    float* db = (float*)(base + stft_bytes);
+    unsigned* maxbits = (unsigned*)(base + stft_bytes +
+                                    align256((size_t)B * BINS * T * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(maxbits, 0, B * sizeof(unsigned), s));
+    int rc = stft_launch(2, audio, db, maxbits, B, N, base, stft_bytes, s);
+    if (rc) return rc;
+    LoudnessArgs a;
+    a.db = db; a.maxbits = maxbits; a.weights = a_weights; a.out = out;
+    a.F = BINS; a.T = T; a.bands = bands;
+    const double step = (double)BINS / (double)bands;   // loudness.py:96
+    for (int b = 0; b <= bands && b <= 16; ++b)
+        a.band_start[b] = (int)(b * step);
+    if (bands == 1) { a.band_start[0] = 0; a.band_start[1] = BINS; }
+    a.min_db = min_db; a.top_db = 80.f;
+    hipLaunchKernelGGL(pm_loudness_bands_kernel, dim3((T + 255) / 256, bands, B),
+                       dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}

@@ -1,0 +1,96 @@
+// Shared device helpers for the promonet MI355X (gfx950 / CDNA4) kernels.
+//
+// Layout convention used by every kernel in this library: activations are
+// CHANNELS-LAST, (B, L, C) with C contiguous and padded to a multiple of 32.
+// A time tile of TL positions x C channels is one contiguous run in HBM
+// (coalesced), a convolution tap / dilation is a pure ROW offset, and one
+// lane's MFMA operand (8 consecutive input channels at one time position)
+// is one 16-byte LDS read.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PM_LRELU_SLOPE 0.1f   // promonet/config/defaults.py:216
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pm_lrelu(float v) {
+    return v > 0.f ? v : v * PM_LRELU_SLOPE;
+}
+
+// ---------------------------------------------------------------------------
+// Element traits: the MFMA operand type. One "k16 step" contracts 16 input
+// channels for a 32(co) x 32(time) tile:
+//   F16 / BF16 : one v_mfma_f32_32x32x16_{f16,bf16}      (fp32 accumulate)
+//   F32        : eight v_mfma_f32_32x32x2_f32            (exact fp32)
+// In all three the lane (l) holds, for row/col (l & 31), the 8 consecutive
+// k-indices (l >> 5) * 8 + e, e = 0..7 - identical for A and B, so the sum
+// over k is complete whatever order the hardware consumes it in.
+// ---------------------------------------------------------------------------
+struct ElemF16 {
+    typedef _Float16 lds_t;
+    typedef half8 frag_t;
+    static constexpr int ESZ = 2;
+    static constexpr int ID = 1;
+    __device__ static __forceinline__ void mma(
+        const frag_t& a, const frag_t& b, floatx16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void store4(char* p, float4 v) {
+        half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<half4*>(p) = h;
+    }
+    __device__ static __forceinline__ lds_t cvt(float v) { return (_Float16)v; }
+};
+
+struct ElemBF16 {
+    typedef __bf16 lds_t;
+    typedef bf16x8 frag_t;
+    static constexpr int ESZ = 2;
+    static constexpr int ID = 2;
+    __device__ static __forceinline__ void mma(
+        const frag_t& a, const frag_t& b, floatx16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void store4(char* p, float4 v) {
+        bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<bf16x4*>(p) = h;
+    }
+    __device__ static __forceinline__ lds_t cvt(float v) { return (__bf16)v; }
+};
+
+struct ElemF32 {
+    typedef float lds_t;
+    struct frag_t { float4 lo, hi; };
+    static constexpr int ESZ = 4;
+    static constexpr int ID = 0;
+    __device__ static __forceinline__ void mma(
+        const frag_t& a, const frag_t& b, floatx16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.x, b.lo.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.y, b.lo.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.z, b.lo.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.w, b.lo.w, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.x, b.hi.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.y, b.hi.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.z, b.hi.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.w, b.hi.w, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void store4(char* p, float4 v) {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+    __device__ static __forceinline__ lds_t cvt(float v) { return v; }
+};
+
+// Bijective XCD-aware remap of a linear workgroup id: the dispatcher places
+// block b on XCD b % 8; give each XCD a contiguous run of tiles so that
+// neighbouring time tiles (which share halo rows) hit the same L2.
+__device__ __forceinline__ int pm_xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

@@ -1,0 +1,487 @@
+// MFMA implicit-GEMM 1-D convolutions for the HiFi-GAN generator
+// (reference: promonet/model/hifigan.py). Hand-written for gfx950.
+//
+//   out[co, t] = b[co] + sum_{ci, j} w[co, ci, j] * act(x[ci, t + (j - (k-1)/2) d])
+//
+// GEMM view per workgroup: M = output channels (A operand = weights, streamed
+// from L2 straight into registers in a pre-packed fragment layout),
+// N = time (B operand = activation rows staged once in LDS with the dilated
+// halo, LeakyReLU + fp32->operand-type conversion fused into the staging
+// write), K = (input channel, tap). A tap / dilation is a row offset into the
+// LDS tile, so the tile is read k times from LDS and once from HBM.
+//
+// Two kernels:
+//   conv_pair_kernel    one HiFi-GAN `Block` iteration fused:
+//                       y = x + conv2(lrelu(conv1(lrelu(x))))      hifigan.py:198-210
+//                       (conv1 output never leaves LDS), optional MRF
+//                       accumulation epilogue (xs / 3, hifigan.py:141-145)
+//   conv_single_kernel  generic C_in -> M conv with per-M-tile tap windows;
+//                       runs the input conv (hifigan.py:19-24) and, as an
+//                       r-phase polyphase GEMM, the ConvTranspose1d
+//                       upsamplers (hifigan.py:100-106).
+#pragma once
+#include "pm_common.h"
+
+// ---------------------------------------------------------------------------
+// Packed weight layout (built once at load by pm_pack_weights_kernel):
+//   frag[(((mt * NCH + c) * KT + jj) * KC + kc) * 64 + lane] = 8 elements:
+//     co = mt*32 + (lane & 31), ci = c*CH + kc*16 + (lane >> 5)*8 + e, tap jj
+// so one wave's A operand for one k16 step is 64 contiguous fragments.
+// ---------------------------------------------------------------------------
+
+template <class ET, int CH, int NT, int XR_MAX>
+struct ChunkStager {
+    static constexpr int Q = CH / 4;  // float4 per row-chunk
+    static constexpr int MAXIT = (XR_MAX * Q + NT - 1) / NT;
+    static constexpr int S = CH * ET::ESZ + 16;
+    float4 r[MAXIT];
+
+    // Global (fp32, channels-last) -> registers. Rows outside [0, L) are the
+    // convolution's zero padding (true sequence ends only).
+    __device__ __forceinline__ void load(
+        const float* __restrict__ xb, int cstride, int c0, int t_first,
+        int XR, int L, int tid) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx / Q, q = idx % Q;
+            const int t = t_first + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < XR && t >= 0 && t < L)
+                v = *reinterpret_cast<const float4*>(
+                    xb + (size_t)t * cstride + c0 + q * 4);
+            r[it] = v;
+        }
+    }
+
+    // Registers -> LDS with the input activation and operand conversion fused
+    template <bool LRELU>
+    __device__ __forceinline__ void store(char* buf, int XR, int tid) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx / Q, q = idx % Q;
+            if (row < XR) {
+                float4 v = r[it];
+                if (LRELU) {
+                    v.x = pm_lrelu(v.x); v.y = pm_lrelu(v.y);
+                    v.z = pm_lrelu(v.z); v.w = pm_lrelu(v.w);
+                }
+                ET::store4(buf + row * S + q * 4 * ET::ESZ, v);
+            }
+        }
+    }
+};
+
+// All taps x all k16-steps of one staged channel chunk for this wave's
+// MTW x NTW grid of 32x32 tiles. A fragments are double-buffered in
+// registers one group (G steps) ahead of the MFMAs that consume them.
+template <class ET, int KT, int KC, int MTW, int NTW, int G, int S>
+__device__ __forceinline__ void mma_taps(
+    floatx16 (&acc)[MTW][NTW], const char* bptr, const int tap_bytes,
+    const typename ET::frag_t* __restrict__ wptr, const int w_mt_stride) {
+    typedef typename ET::frag_t frag_t;
+    constexpr int NS = KT * KC;
+    static_assert(NS % G == 0, "group size must divide the step count");
+    frag_t abuf[2][G][MTW];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+            abuf[0][g][mt] = wptr[mt * w_mt_stride + g * 64];
+#pragma unroll
+    for (int g0 = 0; g0 < NS; g0 += G) {
+        const int cur = (g0 / G) & 1;
+        if (g0 + G < NS) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+                    abuf[cur ^ 1][g][mt] =
+                        wptr[mt * w_mt_stride + (g0 + G + g) * 64];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int step = g0 + g;
+            const int j = step / KC, kc = step % KC;
+            frag_t b[NTW];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                b[nt] = *reinterpret_cast<const frag_t*>(
+                    bptr + nt * 32 * S + j * tap_bytes + kc * 16 * ET::ESZ);
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    ET::mma(abuf[cur][g][mt], b[nt], acc[mt][nt]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused Block iteration
+// ---------------------------------------------------------------------------
+
+struct PairArgs {
+    const float* x;      // (B, L, C) fp32 trunk (pre-activation)
+    float* out;          // (B, L, C)
+    const void* w1;      // packed conv1 weights (dilated)
+    const void* w2;      // packed conv2 weights (dilation 1)
+    const float* b1;     // (C)
+    const float* b2;     // (C)
+    int B, L;
+    int dilation;
+    int mode;            // 0: out = y; 1: out = y * scale; 2: out += y * scale
+    float scale;
+    int ntiles;          // tiles per utterance
+};
+
+template <int C, int K, int WN, int NTW>
+struct PairGeom {
+    static constexpr int N1 = WN * NTW * 32;   // conv1 output columns
+    static constexpr int TL = N1 - (K - 1);    // valid outputs per tile
+};
+
+template <class ET, int C, int K, int WM, int WN, int NTW>
+__host__ __device__ constexpr int pair_smem_bytes(int d) {
+    constexpr int CH = C < 64 ? C : 64;
+    constexpr int NCH = C / CH;
+    constexpr int N1 = WN * NTW * 32;
+    return (NCH > 1 ? 2 : 1) * (N1 + (K - 1) * d) * (CH * ET::ESZ + 16) +
+           (N1 + K - 1) * (C * ET::ESZ + 16);
+}
+
+template <class ET, int C, int K, int WM, int WN, int NTW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
+    typedef typename ET::frag_t frag_t;
+    constexpr int CH = C < 64 ? C : 64;
+    constexpr int NCH = C / CH;
+    constexpr int KC = CH / 16;
+    constexpr int MT = C / 32;
+    constexpr int MTW = MT / WM;
+    static_assert(MT % WM == 0, "WM must divide the M tile count");
+    constexpr int N1 = WN * NTW * 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int H2 = (K - 1) / 2;
+    constexpr int TL = N1 - (K - 1);
+    constexpr int SX = CH * ET::ESZ + 16;
+    constexpr int SI = C * ET::ESZ + 16;
+    constexpr int XR_MAX = N1 + (K - 1) * 5;
+    constexpr int G = (ET::ESZ == 4) ? (KC >= 2 ? 2 : 1) : KC;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ln = lane & 31, lh = lane >> 5;
+
+    const int wg = pm_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = wg % a.ntiles;
+    const int b = wg / a.ntiles;
+    const int t0 = tile * TL;
+    const int L = a.L;
+    const int d = a.dilation;
+    const int hd = H2 * d;
+    const int XR = N1 + (K - 1) * d;
+
+    char* xbuf = smem;
+    char* inter = smem + (NCH > 1 ? 2 : 1) * XR * SX;
+
+    const float* xb = a.x + (size_t)b * L * C;
+    const int t_first = t0 - H2 - hd;
+
+    floatx16 acc[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // ---------------- conv1: K-loop over staged channel chunks -------------
+    ChunkStager<ET, CH, NT, XR_MAX> stager;
+    stager.load(xb, C, 0, t_first, XR, L, tid);
+    stager.template store<true>(xbuf, XR, tid);
+    __syncthreads();
+
+    const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1) +
+                       (size_t)(wm * MTW) * (NCH * K * KC * 64) + lane;
+    const frag_t* w2 = reinterpret_cast<const frag_t*>(a.w2) +
+                       (size_t)(wm * MTW) * (NCH * K * KC * 64) + lane;
+    constexpr int W_MT_STRIDE = NCH * K * KC * 64;
+    const int lane_off_x =
+        ((wn * NTW * 32) + ln) * SX + lh * 8 * ET::ESZ;
+
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        char* cur = xbuf + (NCH > 1 ? (c & 1) * XR * SX : 0);
+        if (c + 1 < NCH) stager.load(xb, C, (c + 1) * CH, t_first, XR, L, tid);
+        mma_taps<ET, K, KC, MTW, NTW, G, SX>(
+            acc, cur + lane_off_x, d * SX, w1 + (size_t)c * (K * KC * 64),
+            W_MT_STRIDE);
+        if (c + 1 < NCH) {
+            char* nxt = xbuf + ((c + 1) & 1) * XR * SX;
+            stager.template store<true>(nxt, XR, tid);
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue 1: bias, lrelu, zero-pad mask -> LDS --------
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int co_base = (wm * MTW + mt) * 32 + 4 * lh;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = (wn * NTW + nt) * 32 + ln;
+            const int t = t0 - H2 + n;
+            const bool inside = (t >= 0) && (t < L);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int co = co_base + 8 * g4;
+                const float4 bias =
+                    *reinterpret_cast<const float4*>(a.b1 + co);
+                float4 v;
+                v.x = pm_lrelu(acc[mt][nt][4 * g4 + 0] + bias.x);
+                v.y = pm_lrelu(acc[mt][nt][4 * g4 + 1] + bias.y);
+                v.z = pm_lrelu(acc[mt][nt][4 * g4 + 2] + bias.z);
+                v.w = pm_lrelu(acc[mt][nt][4 * g4 + 3] + bias.w);
+                if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                ET::store4(inter + n * SI + co * ET::ESZ, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][4 * g4 + r] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- conv2 (dilation 1) straight out of LDS ---------------
+    const int lane_off_i = ((wn * NTW * 32) + ln) * SI + lh * 8 * ET::ESZ;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        mma_taps<ET, K, KC, MTW, NTW, G, SI>(
+            acc, inter + lane_off_i + c * CH * ET::ESZ, SI,
+            w2 + (size_t)c * (K * KC * 64), W_MT_STRIDE);
+    }
+
+    // ---------------- epilogue 2: bias + residual (+ MRF accumulate) -------
+    float* ob = a.out + (size_t)b * L * C;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int co_base = (wm * MTW + mt) * 32 + 4 * lh;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = (wn * NTW + nt) * 32 + ln;
+            const int t = t0 + n;
+            if (n < TL && t < L) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = co_base + 8 * g4;
+                    const float4 bias =
+                        *reinterpret_cast<const float4*>(a.b2 + co);
+                    const float4 res = *reinterpret_cast<const float4*>(
+                        xb + (size_t)t * C + co);
+                    float4 v;
+                    v.x = acc[mt][nt][4 * g4 + 0] + bias.x + res.x;
+                    v.y = acc[mt][nt][4 * g4 + 1] + bias.y + res.y;
+                    v.z = acc[mt][nt][4 * g4 + 2] + bias.z + res.z;
+                    v.w = acc[mt][nt][4 * g4 + 3] + bias.w + res.w;
+                    float4* dst =
+                        reinterpret_cast<float4*>(ob + (size_t)t * C + co);
+                    if (a.mode == 1) {
+                        v.x *= a.scale; v.y *= a.scale;
+                        v.z *= a.scale; v.w *= a.scale;
+                    } else if (a.mode == 2) {
+                        const float4 o = *dst;
+                        v.x = o.x + v.x * a.scale; v.y = o.y + v.y * a.scale;
+                        v.z = o.z + v.z * a.scale; v.w = o.w + v.w * a.scale;
+                    }
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Generic single convolution / polyphase transposed convolution
+// ---------------------------------------------------------------------------
+
+struct SingleArgs {
+    const float* x;       // (B, L, Cin) fp32
+    float* out;           // (B, L, M) fp32  (for ConvTranspose: (B, L*r, Cout))
+    const void* w;        // packed weights, KT taps per M tile
+    const float* bias;    // (M)
+    const float* gbias;   // (B|1, M) per-utterance bias (speaker conv) or null
+    int gbias_batch;      // 1 -> broadcast row 0
+    int B, L, Cin, M;
+    int Lout;             // output rows per utterance (== L except STFT)
+    int bins;             // EPI 1/2: DFT bins (output (B, bins, Lout))
+    unsigned* maxbits;    // EPI 2: per-utterance max (order-preserving bits)
+    int lrelu;            // apply LeakyReLU to the input while staging
+    int pad;              // rows of left padding of the staged tile
+    // tap window start for an M row block (ConvTranspose phases): window
+    // starts at tap 1 when ((m / phase_c) + phase_p >= phase_r), else 0;
+    // phase_r == 0 disables (plain conv, window = all KT taps from 0)
+    int phase_c, phase_p, phase_r;
+    int ntiles, nmblocks;
+};
+
+// KT: taps contracted per M tile; KSPAN: taps spanned by the staged halo
+// (KSPAN == KT for a plain conv, 3 for the 2-tap polyphase ConvTranspose).
+// EPI 0: out (B, Lout, M) = acc + bias (+ per-utterance bias)
+// EPI 1: framed-DFT magnitude: M rows are (re, im) pairs of one bin,
+//        out (B, bins, Lout) = sqrt(re^2 + im^2 + 1e-6)   spectrogram.py:53
+// EPI 2: out (B, bins, Lout) = 10 log10(max(1e-10, re^2 + im^2)) and the
+//        per-utterance maximum (librosa.amplitude_to_db, loudness.py:46)
+__device__ __forceinline__ unsigned pm_float_order_bits(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <class ET, int KT, int KSPAN, int CH, int WM, int WN, int MTW, int NTW,
+          int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
+    SingleArgs a) {
+    typedef typename ET::frag_t frag_t;
+    constexpr int KC = CH / 16;
+    constexpr int N1 = WN * NTW * 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int SX = CH * ET::ESZ + 16;
+    constexpr int XR = N1 + KSPAN - 1;
+    constexpr int MB = WM * MTW * 32;
+    constexpr int G = (ET::ESZ == 4) ? (KC >= 2 ? 2 : 1) : KC;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ln = lane & 31, lh = lane >> 5;
+
+    const int wg = pm_xcd_remap(blockIdx.x, gridDim.x);
+    const int mb = wg % a.nmblocks;
+    const int tile = (wg / a.nmblocks) % a.ntiles;
+    const int b = wg / (a.nmblocks * a.ntiles);
+    const int t0 = tile * N1;
+    const int L = a.L, Cin = a.Cin, M = a.M;
+    const int NCH = Cin / CH;
+    const int m0 = mb * MB + wm * MTW * 32;   // this wave's first M row
+    int js = 0;
+    if (a.phase_r > 0 && (m0 / a.phase_c) + a.phase_p >= a.phase_r) js = 1;
+
+    const float* xb = a.x + (size_t)b * L * Cin;
+    const int t_first = t0 - a.pad;
+
+    floatx16 acc[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    ChunkStager<ET, CH, NT, XR> stager;
+    stager.load(xb, Cin, 0, t_first, XR, L, tid);
+    if (a.lrelu) stager.template store<true>(smem, XR, tid);
+    else stager.template store<false>(smem, XR, tid);
+    __syncthreads();
+
+    const int w_mt_stride = NCH * KT * KC * 64;
+    const frag_t* w = reinterpret_cast<const frag_t*>(a.w) +
+                      (size_t)(m0 / 32) * w_mt_stride + lane;
+    const int lane_off_x =
+        ((wn * NTW * 32) + ln + js) * SX + lh * 8 * ET::ESZ;
+
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        char* cur = smem + (c & 1) * XR * SX;
+        if (c + 1 < NCH)
+            stager.load(xb, Cin, (c + 1) * CH, t_first, XR, L, tid);
+        mma_taps<ET, KT, KC, MTW, NTW, G, SX>(
+            acc, cur + lane_off_x, SX, w + (size_t)c * (KT * KC * 64),
+            w_mt_stride);
+        if (c + 1 < NCH) {
+            char* nxt = smem + ((c + 1) & 1) * XR * SX;
+            if (a.lrelu) stager.template store<true>(nxt, XR, tid);
+            else stager.template store<false>(nxt, XR, tid);
+            __syncthreads();
+        }
+    }
+
+    if constexpr (EPI == 0) {
+    float* ob = a.out + (size_t)b * a.Lout * M;
+    const float* gb = a.gbias
+        ? a.gbias + (size_t)(a.gbias_batch == 1 ? 0 : b) * M : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int co_base = m0 + mt * 32 + 4 * lh;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = (wn * NTW + nt) * 32 + ln;
+            const int t = t0 + n;
+            if (t < a.Lout) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = co_base + 8 * g4;
+                    float4 bias =
+                        *reinterpret_cast<const float4*>(a.bias + co);
+                    if (gb) {
+                        const float4 g =
+                            *reinterpret_cast<const float4*>(gb + co);
+                        bias.x += g.x; bias.y += g.y;
+                        bias.z += g.z; bias.w += g.w;
+                    }
+                    float4 v;
+                    v.x = acc[mt][nt][4 * g4 + 0] + bias.x;
+                    v.y = acc[mt][nt][4 * g4 + 1] + bias.y;
+                    v.z = acc[mt][nt][4 * g4 + 2] + bias.z;
+                    v.w = acc[mt][nt][4 * g4 + 3] + bias.w;
+                    *reinterpret_cast<float4*>(ob + (size_t)t * M + co) = v;
+                }
+            }
+        }
+    }
+    } else {
+    float* ob = a.out + (size_t)b * a.bins * a.Lout;
+    float local_max = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int row_base = m0 + mt * 32 + 4 * lh;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = (wn * NTW + nt) * 32 + ln;
+            const int t = t0 + n;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int bin = (row_base + 8 * g4) / 2 + pr;
+                    const float re = acc[mt][nt][4 * g4 + 2 * pr];
+                    const float im = acc[mt][nt][4 * g4 + 2 * pr + 1];
+                    const float pw = re * re + im * im;
+                    if (t < a.Lout && bin < a.bins) {
+                        float v;
+                        if constexpr (EPI == 1) {
+                            v = sqrtf(pw + 1e-6f);
+                        } else {
+                            v = 10.f * log10f(fmaxf(1e-10f, pw));
+                            local_max = fmaxf(local_max, v);
+                        }
+                        ob[(size_t)bin * a.Lout + t] = v;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            local_max = fmaxf(local_max, __shfl_xor(local_max, o, 64));
+        if (lane == 0 && local_max > -INFINITY)
+            atomicMax(a.maxbits + b, pm_float_order_bits(local_max));
+    }
+    }
+}

@@ -1,0 +1,6 @@
+// Explicit instantiation of the MFMA convolution launchers for ElemBF16.
+#define PM_INSTANTIATE
+#include "pm_launch.h"
+template hipError_t pm_launch_pair<ElemBF16>(int, int, const PairArgs&, hipStream_t);
+template int pm_pair_tile_len<ElemBF16>(int, int);
+template hipError_t pm_launch_single<ElemBF16>(int, int, int, const SingleArgs&, hipStream_t);

@@ -1,0 +1,7 @@
+// Explicit instantiation of the MFMA convolution launchers for ElemF32.
+#define PM_INSTANTIATE
+#define PM_INSTANTIATE_STFT
+#include "pm_launch.h"
+template hipError_t pm_launch_pair<ElemF32>(int, int, const PairArgs&, hipStream_t);
+template int pm_pair_tile_len<ElemF32>(int, int);
+template hipError_t pm_launch_single<ElemF32>(int, int, int, const SingleArgs&, hipStream_t);

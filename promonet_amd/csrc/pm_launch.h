@@ -1,0 +1,150 @@
+// Host-side launchers: pick the template instantiation (tile geometry) for a
+// layer shape. Explicitly instantiated once per operand type in
+// pm_conv_{f16,bf16,f32}.hip so the three compile in parallel.
+#pragma once
+#include "pm_conv.h"
+
+template <class ET> hipError_t pm_launch_pair(
+    int C, int K, const PairArgs& args, hipStream_t stream);
+template <class ET> int pm_pair_tile_len(int C, int K);
+
+// kind 0: plain conv with KT = KSPAN = 7 (input conv); kind 1: polyphase
+// ConvTranspose (KT = 2, KSPAN = 3). cfg: 0 = 256 x 128 tile, 1 = 64 x 128,
+// 2 = 32 x 128.
+template <class ET> hipError_t pm_launch_single(
+    int kind, int ch, int cfg, const SingleArgs& args, hipStream_t stream);
+hipError_t pm_launch_stft(int epi, const SingleArgs& args, hipStream_t stream);
+
+#ifdef PM_INSTANTIATE
+
+// ---- fused pair geometry per (operand type, C) ---------------------------
+template <class ET, int C> struct PairCfg;
+// 16-bit operands: 128-column tiles everywhere
+template <> struct PairCfg<ElemF16, 256> { enum { WM = 4, WN = 2, NTW = 2 }; };
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2 }; };
+template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2 }; };
+template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1 }; };
+template <int C> struct PairCfg<ElemBF16, C> : PairCfg<ElemF16, C> {};
+// exact fp32 operands: LDS rows are twice as wide -> 64-column tiles
+template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1 }; };
+template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1 }; };
+template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1 }; };
+template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1 }; };
+
+template <class ET, int C, int K>
+static hipError_t launch_pair_ck(const PairArgs& a0, hipStream_t stream) {
+    typedef PairCfg<ET, C> G;
+    constexpr int WM = G::WM, WN = G::WN, NTW = G::NTW;
+    constexpr int TL = WN * NTW * 32 - (K - 1);
+    PairArgs a = a0;
+    a.ntiles = (a.L + TL - 1) / TL;
+    auto kern = conv_pair_kernel<ET, C, K, WM, WN, NTW>;
+    const int smem = pair_smem_bytes<ET, C, K, WM, WN, NTW>(a.dilation);
+    static int max_set = 0;
+    if (smem > max_set) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(kern),
+            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        max_set = smem;
+    }
+    const int grid = a.ntiles * a.B;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <class ET, int C>
+static hipError_t launch_pair_c(int K, const PairArgs& a, hipStream_t s) {
+    switch (K) {
+        case 3: return launch_pair_ck<ET, C, 3>(a, s);
+        case 7: return launch_pair_ck<ET, C, 7>(a, s);
+        case 11: return launch_pair_ck<ET, C, 11>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <class ET>
+hipError_t pm_launch_pair(int C, int K, const PairArgs& a, hipStream_t s) {
+    switch (C) {
+        case 256: return launch_pair_c<ET, 256>(K, a, s);
+        case 128: return launch_pair_c<ET, 128>(K, a, s);
+        case 64: return launch_pair_c<ET, 64>(K, a, s);
+        case 32: return launch_pair_c<ET, 32>(K, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <class ET>
+int pm_pair_tile_len(int C, int K) {
+    switch (C) {
+        case 256: return PairCfg<ET, 256>::WN * PairCfg<ET, 256>::NTW * 32 - (K - 1);
+        case 128: return PairCfg<ET, 128>::WN * PairCfg<ET, 128>::NTW * 32 - (K - 1);
+        case 64: return PairCfg<ET, 64>::WN * PairCfg<ET, 64>::NTW * 32 - (K - 1);
+        case 32: return PairCfg<ET, 32>::WN * PairCfg<ET, 32>::NTW * 32 - (K - 1);
+    }
+    return 0;
+}
+
+// ---- single conv ----------------------------------------------------------
+template <class ET, int KT, int KSPAN, int CH, int WM, int WN, int MTW, int NTW,
+          int EPI = 0>
+static hipError_t launch_single_cfg(const SingleArgs& a0, hipStream_t stream) {
+    constexpr int N1 = WN * NTW * 32;
+    constexpr int MB = WM * MTW * 32;
+    SingleArgs a = a0;
+    a.ntiles = (a.Lout + N1 - 1) / N1;
+    a.nmblocks = a.M / MB;
+    auto kern = conv_single_kernel<ET, KT, KSPAN, CH, WM, WN, MTW, NTW, EPI>;
+    constexpr int smem = 2 * (N1 + KSPAN - 1) * (CH * ET::ESZ + 16);
+    static bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(kern),
+            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = a.ntiles * a.nmblocks * a.B;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <class ET, int KT, int KSPAN>
+static hipError_t launch_single_k(
+    int ch, int cfg, const SingleArgs& a, hipStream_t s) {
+    if (ch == 64) {
+        switch (cfg) {
+            case 0: return launch_single_cfg<ET, KT, KSPAN, 64, 4, 2, 2, 2>(a, s);
+            case 1: return launch_single_cfg<ET, KT, KSPAN, 64, 2, 2, 1, 2>(a, s);
+            case 2: return launch_single_cfg<ET, KT, KSPAN, 64, 1, 4, 1, 1>(a, s);
+        }
+    } else if (ch == 32) {
+        switch (cfg) {
+            case 1: return launch_single_cfg<ET, KT, KSPAN, 32, 2, 2, 1, 2>(a, s);
+            case 2: return launch_single_cfg<ET, KT, KSPAN, 32, 1, 4, 1, 1>(a, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+template <class ET>
+hipError_t pm_launch_single(
+    int kind, int ch, int cfg, const SingleArgs& a, hipStream_t s) {
+    if (kind == 0) return launch_single_k<ET, 7, 7>(ch, cfg, a, s);
+    if (kind == 1) return launch_single_k<ET, 2, 3>(ch, cfg, a, s);
+    return hipErrorInvalidValue;
+}
+
+// Framed DFT (STFT) as a 4-tap conv over the hop-reshaped padded audio:
+// exact-fp32 MFMA only. epi 1: magnitude, 2: dB + utterance max.
+#ifdef PM_INSTANTIATE_STFT
+hipError_t pm_launch_stft(int epi, const SingleArgs& a, hipStream_t s) {
+    if (epi == 1)
+        return launch_single_cfg<ElemF32, 4, 4, 64, 2, 2, 1, 2, 1>(a, s);
+    if (epi == 2)
+        return launch_single_cfg<ElemF32, 4, 4, 64, 2, 2, 1, 2, 2>(a, s);
+    return hipErrorInvalidValue;
+}
+#endif
+
+#endif  // PM_INSTANTIATE

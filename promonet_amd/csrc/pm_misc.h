@@ -1,0 +1,300 @@
+// Streaming (HBM-bound) kernels around the MFMA convolutions: weight
+// folding / packing (load time), conditioning-feature preparation, speaker
+// bias, output conv + tanh. Reference: promonet/model/generator.py,
+// promonet/model/hifigan.py.
+#pragma once
+#include "pm_common.h"
+
+// ---------------------------------------------------------------------------
+// weight_norm fold: w[r, :] = v[r, :] * g[r] / ||v[r, :]||   (dim = 0)
+// torch.nn.utils.weight_norm as used at model/core.py:43-45 and
+// model/hifigan.py:100-106. One workgroup per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pm_fold_kernel(
+    const float* __restrict__ g, const float* __restrict__ v,
+    float* __restrict__ w, int cols) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* vr = v + (size_t)row * cols;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256) s += vr[i] * vr[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float scale = g[row] / norm;
+    for (int i = threadIdx.x; i < cols; i += 256)
+        w[(size_t)row * cols + i] = vr[i] * scale;
+}
+
+// ---------------------------------------------------------------------------
+// Pack torch-layout fp32 weights into the MFMA A-fragment stream of
+// pm_conv.h. One thread per packed element.
+//   mode 0: Conv1d           w[co][ci][k]   -> taps jj = 0..KT-1
+//   mode 1: ConvTranspose1d  w[ci][co][k], stride r, pad p = (k - r) / 2,
+//           M row m = ph * cout_pad + co; two taps per phase:
+//           s = ph + p; window start js = (s >= r); tap jt = js + jj reads
+//           input q - 1 + jt with kernel index (1 - jt) * r + s
+// ---------------------------------------------------------------------------
+struct PackArgs {
+    const float* w;
+    void* out;
+    int mode;
+    int cout, cin, k;          // actual (unpadded) torch dims
+    int cout_pad, cin_pad;     // padded
+    int mtiles, nch, ch, kt;   // packed geometry (kc = ch / 16)
+    int r, p;                  // ConvTranspose stride / padding
+    long long total;           // packed elements
+};
+
+template <class ET>
+__global__ __launch_bounds__(256) void pm_pack_kernel(PackArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.total) return;
+    const int kc_n = a.ch / 16;
+    long long rem = idx;
+    const int e = rem % 8; rem /= 8;
+    const int lane = rem % 64; rem /= 64;
+    const int kc = rem % kc_n; rem /= kc_n;
+    const int jj = rem % a.kt; rem /= a.kt;
+    const int c = rem % a.nch; rem /= a.nch;
+    const int mt = (int)rem;
+    const int m = mt * 32 + (lane & 31);
+    const int ci = c * a.ch + kc * 16 + (lane >> 5) * 8 + e;
+    float v = 0.f;
+    if (a.mode == 0) {
+        if (m < a.cout && ci < a.cin)
+            v = a.w[((size_t)m * a.cin + ci) * a.k + jj];
+    } else {
+        const int ph = m / a.cout_pad, co = m % a.cout_pad;
+        const int s = ph + a.p;
+        const int js = s >= a.r ? 1 : 0;
+        const int jt = js + jj;
+        const int jw = (1 - jt) * a.r + s;
+        if (co < a.cout && ci < a.cin && jw >= 0 && jw < a.k)
+            v = a.w[((size_t)ci * a.cout + co) * a.k + jw];
+    }
+    reinterpret_cast<typename ET::lds_t*>(a.out)[idx] = ET::cvt(v);
+}
+
+// dst[i] = i < n ? src[i] : 0  for i < n_pad; optionally tiled `rep` times
+__global__ void pm_pad_bias_kernel(
+    const float* __restrict__ src, float* __restrict__ dst, int n, int n_pad,
+    int rep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad * rep) return;
+    const int c = i % n_pad;
+    dst[i] = (src && c < n) ? src[c] : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// (B, C, T) fp32 -> (B, T, Cpad) fp32 channels-last, zero padded.
+// The module-seam entry HiFiGAN.forward(x (B,113,T), ...) hifigan.py:63.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pm_to_channels_last_kernel(
+    const float* __restrict__ src, float* __restrict__ dst, int C, int T,
+    int Cpad) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        tile[i][tx] = (c < C && t < T) ? src[((size_t)b * C + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        if (t < T && c < Cpad) dst[((size_t)b * T + t) * Cpad + c] = tile[tx][i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Generator.prepare_features  (model/generator.py:137-197, default config)
+// One thread per frame; the frame's PPG column lives in LDS.
+//   channels [ppg 0:40 | pitch embedding 40:104 | loudness 104:112 | per 112]
+// ---------------------------------------------------------------------------
+struct FeatureArgs {
+    const float* loudness;     // (B, F, T) dB, F = 8 or 513 (any >= bands)
+    const float* pitch;        // (B, T) Hz
+    const float* periodicity;  // (B, T)
+    const float* ppg;          // (B, P, T)
+    const float* pitch_edges;  // (NB) ascending bin edges (load.py:54-74)
+    const float* pitch_table;  // (NB, E) embedding
+    float* out_cl;             // (B, T, Cpad) or null
+    float* out_ref;            // (B, P + E + bands + 1, T) or null
+    int B, T, F, P, NB, E, bands, Cpad;
+    int band_start[17];        // int(b * F / bands), b = 0..bands
+    int rank_below, rank_above;  // torch.quantile(linear) gather indices
+    float rank_weight;
+    float fmin, fmax, min_db, db_range;
+};
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void pm_prepare_features_kernel(
+    FeatureArgs a) {
+    extern __shared__ float col[];  // [P][THREADS]
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * THREADS + threadIdx.x;
+    const int tx = threadIdx.x;
+    const int T = a.T, P = a.P;
+    if (t >= T) return;
+    const int C = P + a.E + a.bands + 1;
+    float* ocl = a.out_cl ? a.out_cl + ((size_t)b * T + t) * a.Cpad : nullptr;
+    float* oref = a.out_ref ? a.out_ref + (size_t)b * C * T + t : nullptr;
+
+    // --- ppgs.sparsify(ppg, 'percentile', 0.85)  (generator.py:140-147) ---
+    const float* pp = a.ppg + (size_t)b * P * T + t;
+    for (int i = 0; i < P; ++i) col[i * THREADS + tx] = pp[(size_t)i * T];
+    float below = 0.f, above = 0.f;
+    for (int i = 0; i < P; ++i) {
+        const float vi = col[i * THREADS + tx];
+        int rank = 0;
+        for (int j = 0; j < P; ++j) {
+            const float vj = col[j * THREADS + tx];
+            rank += (vj < vi) || (vj == vi && j < i);
+        }
+        if (rank == a.rank_below) below = vi;
+        if (rank == a.rank_above) above = vi;
+    }
+    // torch lerp (weight < 0.5 branch is the one 0.85 * 39 takes)
+    const float wq = a.rank_weight;
+    const float q = wq < 0.5f ? below + wq * (above - below)
+                              : above - (above - below) * (1.f - wq);
+    float mx = -INFINITY;
+    for (int i = 0; i < P; ++i) {
+        float v = col[i * THREADS + tx];
+        v = v > q ? v : 0.f;
+        v = logf(v + 1e-8f);
+        col[i * THREADS + tx] = v;
+        mx = fmaxf(mx, v);
+    }
+    float sum = 0.f;
+    for (int i = 0; i < P; ++i) {
+        const float ev = expf(col[i * THREADS + tx] - mx);
+        col[i * THREADS + tx] = ev;
+        sum += ev;
+    }
+    for (int i = 0; i < P; ++i) {
+        const float v = col[i * THREADS + tx] / sum;
+        if (ocl) ocl[i] = v;
+        if (oref) oref[(size_t)i * T] = v;
+    }
+
+    // --- pitch: clip, searchsorted(right=False), clip, embed (:152-164) ---
+    float hz = a.pitch[(size_t)b * T + t];
+    hz = fminf(fmaxf(hz, a.fmin), a.fmax);
+    int lo = 0, hi = a.NB;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a.pitch_edges[mid] < hz) lo = mid + 1; else hi = mid;
+    }
+    const int bin = lo > a.NB - 1 ? a.NB - 1 : lo;
+    const float* emb = a.pitch_table + (size_t)bin * a.E;
+    for (int i = 0; i < a.E; ++i) {
+        const float v = emb[i];
+        if (ocl) ocl[P + i] = v;
+        if (oref) oref[(size_t)(P + i) * T] = v;
+    }
+
+    // --- loudness band means + normalize (:172-184, loudness.py:144-146) ---
+    const float* lp = a.loudness + (size_t)b * a.F * T + t;
+    for (int band = 0; band < a.bands; ++band) {
+        float s = 0.f;
+        const int r0 = a.band_start[band], r1 = a.band_start[band + 1];
+        for (int r = r0; r < r1; ++r) s += lp[(size_t)r * T];
+        const float v = (s / (float)(r1 - r0) - a.min_db) / a.db_range;
+        if (ocl) ocl[P + a.E + band] = v;
+        if (oref) oref[(size_t)(P + a.E + band) * T] = v;
+    }
+
+    // --- periodicity (:187-188) + zero channel padding ---
+    const float per = a.periodicity[(size_t)b * T + t];
+    if (ocl) {
+        ocl[C - 1] = per;
+        for (int i = C; i < a.Cpad; ++i) ocl[i] = 0.f;
+    }
+    if (oref) oref[(size_t)(C - 1) * T] = per;
+}
+
+// ---------------------------------------------------------------------------
+// prepare_global_features (generator.py:49-70): embedding row + two ratios
+// ---------------------------------------------------------------------------
+__global__ void pm_global_features_kernel(
+    const long long* __restrict__ speakers, const float* __restrict__ sbr,
+    const float* __restrict__ lr, const float* __restrict__ table,
+    float* __restrict__ out, int B, int S) {
+    const int b = blockIdx.x;
+    const long long spk = speakers[b];
+    for (int i = threadIdx.x; i < S; i += blockDim.x)
+        out[(size_t)b * (S + 2) + i] = table[(size_t)spk * S + i];
+    if (threadIdx.x == 0) {
+        out[(size_t)b * (S + 2) + S] = sbr[b];
+        out[(size_t)b * (S + 2) + S + 1] = lr[b];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// input_speaker_conv: 1x1 conv on (B|1, G, 1)  (hifigan.py:26-30, 68)
+//   gbias[b][m] = bs[m] + sum_c Ws[m][c] g[b][c]      one wave per (b, m)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pm_speaker_bias_kernel(
+    const float* __restrict__ g, const float* __restrict__ ws,
+    const float* __restrict__ bs, float* __restrict__ out, int G, int M,
+    int Mpad) {
+    const int b = blockIdx.y;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (m >= Mpad) return;
+    float s = 0.f;
+    if (m < M)
+        for (int c = lane; c < G; c += 64)
+            s += ws[(size_t)m * G + c] * g[(size_t)b * G + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) out[(size_t)b * Mpad + m] = m < M ? s + bs[m] : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// Output layer: LeakyReLU -> Conv1d(C -> 1, k 7, pad 3, no bias) -> tanh
+// (hifigan.py:55-60). HBM-bound: reads C floats, writes 1 per sample.
+// ---------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void pm_out_conv_kernel(
+    const float* __restrict__ x, const float* __restrict__ w,
+    float* __restrict__ y, int L, int C, int Cw) {
+    extern __shared__ float sm[];
+    constexpr int KW = 7, HALO = 3;
+    const int S = C + 1;
+    float* xs = sm;                       // [(THREADS + 6)][C + 1]
+    float* wsm = sm + (THREADS + 2 * HALO) * S;   // [KW][C]
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * THREADS;
+    const float* xb = x + (size_t)b * L * C;
+    for (int i = threadIdx.x; i < KW * C; i += THREADS) {
+        const int j = i / C, c = i % C;
+        wsm[i] = c < Cw ? w[c * KW + j] : 0.f;
+    }
+    const int Q = C / 4;
+    for (int i = threadIdx.x; i < (THREADS + 2 * HALO) * Q; i += THREADS) {
+        const int row = i / Q, q = i % Q;
+        const int t = t0 - HALO + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < L)
+            v = *reinterpret_cast<const float4*>(xb + (size_t)t * C + q * 4);
+        float* d = xs + row * S + q * 4;
+        d[0] = pm_lrelu(v.x); d[1] = pm_lrelu(v.y);
+        d[2] = pm_lrelu(v.z); d[3] = pm_lrelu(v.w);
+    }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t >= L) return;
+    float acc = 0.f;
+    for (int j = 0; j < KW; ++j) {
+        const float* xr = xs + (threadIdx.x + j) * S;
+        const float* wr = wsm + j * C;
+        for (int c = 0; c < C; ++c) acc = fmaf(wr[c], xr[c], acc);
+    }
+    y[(size_t)b * L + t] = tanhf(acc);
+}

@@ -1,0 +1,100 @@
+// Framed STFT / mel / A-weighted loudness preprocessing kernels.
+// Reference: promonet/preprocess/spectrogram.py, promonet/preprocess/loudness.py
+//
+// The 1024-point hann-windowed DFT at hop 256 is a 4-tap convolution over the
+// padded audio viewed as (frames + 3, 256) "channels-last" rows, so it runs on
+// the exact-fp32 MFMA conv kernel (pm_conv.h, EPI 1/2) against a precomputed
+// (re, im)-interleaved windowed DFT basis; magnitude / dB conversion happen in
+// the MFMA epilogue and the spectrogram is written once, (B, 513, T).
+#pragma once
+#include "pm_common.h"
+
+// torch.nn.functional.pad(audio, (p, p), mode='reflect') (spectrogram.py:36-37,
+// loudness.py:20-25): (B, N) -> (B, N + 2 p)
+__global__ __launch_bounds__(256) void pm_reflect_pad_kernel(
+    const float* __restrict__ src, float* __restrict__ dst, int N, int pad,
+    int Np) {
+    // Np <= N + 2 pad: number of padded samples kept per utterance
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    int j = i - pad;
+    if (j < 0) j = -j;
+    if (j >= N) j = 2 * (N - 1) - j;
+    dst[(size_t)b * Np + i] = src[(size_t)b * N + j];
+}
+
+// Windowed DFT basis in torch Conv1d layout w[m][c][j], m = 2 bin + part,
+// sample n = j * hop + c: hann(n) cos(2 pi bin n / nfft) | -hann(n) sin(...)
+// hann = periodic (torch.hann_window(1024), spectrogram.py:29).
+__global__ __launch_bounds__(256) void pm_dft_basis_kernel(
+    float* __restrict__ w, int bins, int nfft, int hop) {
+    const int taps = nfft / hop;
+    const long long total = 2LL * bins * nfft;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx % taps;
+    const int c = (idx / taps) % hop;
+    const int m = idx / ((long long)taps * hop);
+    const int bin = m >> 1, part = m & 1;
+    const int n = j * hop + c;
+    const double pi2 = 6.283185307179586476925286766559;
+    const double win = 0.5 - 0.5 * cos(pi2 * n / nfft);
+    // reduce the phase exactly before the trig call
+    const int ph = (int)(((long long)bin * n) % nfft);
+    const double ang = pi2 * ph / nfft;
+    w[idx] = (float)(part == 0 ? win * cos(ang) : -win * sin(ang));
+}
+
+// linear_to_mel (spectrogram.py:111-133): out[b][m][t] = log(sum_f
+// basis[m][f] spec[b][f][t]) with optional clamp. One thread per (m, t).
+__global__ __launch_bounds__(256) void pm_mel_kernel(
+    const float* __restrict__ spec, const float* __restrict__ basis,
+    float* __restrict__ out, int F, int M, int T, int use_thr, float thr) {
+    const int b = blockIdx.z, m = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const float* sp = spec + (size_t)b * F * T + t;
+    const float* br = basis + (size_t)m * F;
+    float acc = 0.f;
+    for (int f = 0; f < F; ++f) acc = fmaf(br[f], sp[(size_t)f * T], acc);
+    float v = logf(acc);
+    if (use_thr) v = fmaxf(v, thr);
+    out[((size_t)b * M + m) * T + t] = v;
+}
+
+__device__ __forceinline__ float pm_float_from_order_bits(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// loudness.from_audio tail (loudness.py:46-55) + band_average (:84-111):
+// db (B, F, T) -> max(db, gmax - 80) + a_weight[f], floored at min_db, then
+// mean over band rows [start[b], start[b+1]).
+struct LoudnessArgs {
+    const float* db;
+    const unsigned* maxbits;
+    const float* weights;
+    float* out;
+    int F, T, bands;
+    int band_start[17];
+    float min_db, top_db;
+};
+
+__global__ __launch_bounds__(256) void pm_loudness_bands_kernel(
+    LoudnessArgs a) {
+    const int b = blockIdx.z, band = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.T) return;
+    const float floor_db = pm_float_from_order_bits(a.maxbits[b]) - a.top_db;
+    const float* dp = a.db + (size_t)b * a.F * a.T + t;
+    // bands == F: no averaging (`bands=None` in the reference API)
+    const int r0 = a.bands == a.F ? band : a.band_start[band];
+    const int r1 = a.bands == a.F ? band + 1 : a.band_start[band + 1];
+    float s = 0.f;
+    for (int f = r0; f < r1; ++f) {
+        float v = fmaxf(dp[(size_t)f * a.T], floor_db) + a.weights[f];
+        v = v < a.min_db ? a.min_db : v;
+        s += v;
+    }
+    a.out[((size_t)b * a.bands + band) * a.T + t] = s / (float)(r1 - r0);
+}

@@ -1,0 +1,142 @@
+"""Generator = feature preparation + vocoder, on the HIP engine.
+
+Drop-in for `promonet.model.Generator` (promonet/model/generator.py:84-197):
+no-argument constructor from the import-time config, the 8-argument
+`forward`, `prepare_features` / `prepare_global_features`, the same
+`state_dict()` keys and buffers.
+"""
+import numpy as np
+import torch
+
+import promonet_amd
+from promonet_amd import _lib
+from .hifigan import HiFiGAN
+
+
+class Generator(torch.nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        if promonet_amd.MODEL != 'hifigan':
+            raise ValueError(
+                f'Generator model {promonet_amd.MODEL} is not defined '
+                '(promonet_amd implements the hifigan hot path)')
+        if promonet_amd.ZERO_SHOT:
+            raise ValueError('ZERO_SHOT speaker embeddings are not supported')
+        self.model = HiFiGAN(
+            promonet_amd.NUM_FEATURES, promonet_amd.GLOBAL_CHANNELS)
+
+        # generator.py:35-42, 92-95: torch.nn.Embedding default init N(0, 1)
+        self.speaker_embedding = torch.nn.Embedding(
+            promonet_amd.NUM_SPEAKERS, promonet_amd.SPEAKER_CHANNELS)
+        self.pitch_embedding = torch.nn.Embedding(
+            promonet_amd.PITCH_BINS, promonet_amd.PITCH_EMBEDDING_SIZE)
+        for parameter in self.parameters():
+            parameter.requires_grad_(False)
+
+        # generator.py:45-47, 101-104, 112-114
+        self.register_buffer(
+            'default_previous_samples',
+            torch.zeros(1, 1, promonet_amd.NUM_PREVIOUS_SAMPLES))
+        self.register_buffer(
+            'ppg_threshold',
+            torch.tensor(promonet_amd.SPARSE_PPG_THRESHOLD, dtype=torch.float))
+        self.register_buffer(
+            'pitch_distribution', promonet_amd.load.pitch_distribution())
+
+    ###########################################################################
+    # Forward (generator.py:116-135)
+    ###########################################################################
+
+    def forward(
+        self,
+        loudness,
+        pitch,
+        periodicity,
+        ppg,
+        speakers,
+        spectral_balance_ratios,
+        loudness_ratios,
+        previous_samples=None
+    ):
+        features_cl = self._features(
+            loudness, pitch, periodicity, ppg, channels_last=True)
+        global_features = self.prepare_global_features(
+            speakers, spectral_balance_ratios, loudness_ratios)
+        return self.model.forward_channels_last(features_cl, global_features)
+
+    def prepare_features(self, loudness, pitch, periodicity, ppg):
+        """(B, 113, T) conditioning tensor (generator.py:137-197)."""
+        return self._features(
+            loudness, pitch, periodicity, ppg, channels_last=False)
+
+    def _features(self, loudness, pitch, periodicity, ppg, channels_last):
+        lib = _lib.lib()
+        if loudness.ndim == 2:
+            loudness = loudness[None]
+        loudness = loudness.to(torch.float32).contiguous()
+        pitch = pitch.to(torch.float32).contiguous()
+        periodicity = periodicity.to(torch.float32).contiguous()
+        ppg = ppg.to(torch.float32).contiguous()
+        batch, rows, frames = loudness.shape
+        channels = ppg.shape[1]
+        if pitch.shape != (batch, frames) or \
+                periodicity.shape != (batch, frames) or \
+                ppg.shape != (batch, channels, frames):
+            raise ValueError('feature shapes disagree')
+        total = (
+            channels + promonet_amd.PITCH_EMBEDDING_SIZE +
+            promonet_amd.LOUDNESS_BANDS + 1)
+        device = pitch.device
+        edges = self.pitch_distribution.to(torch.float32).contiguous()
+        table = self.pitch_embedding.weight.detach().to(
+            torch.float32).contiguous()
+        if channels_last:
+            cpad = (total + 31) // 32 * 32
+            out = torch.empty(batch, frames, cpad, device=device)
+            out_ref, out_cl = None, _lib.ptr(out)
+        else:
+            cpad = 0
+            out = torch.empty(batch, total, frames, device=device)
+            out_ref, out_cl = _lib.ptr(out), None
+        with torch.cuda.device(device):
+            _lib.check(lib.pm_prepare_features(
+                _lib.ptr(loudness), _lib.ptr(pitch), _lib.ptr(periodicity),
+                _lib.ptr(ppg), _lib.ptr(edges), _lib.ptr(table), out_ref,
+                out_cl, batch, frames, rows, channels,
+                promonet_amd.PITCH_BINS, promonet_amd.PITCH_EMBEDDING_SIZE,
+                promonet_amd.LOUDNESS_BANDS, cpad,
+                float(np.float32(self.ppg_threshold.item())),
+                promonet_amd.FMIN, promonet_amd.FMAX, promonet_amd.MIN_DB,
+                promonet_amd.REF_DB, _lib.stream()))
+        return out
+
+    def prepare_global_features(
+        self,
+        speakers,
+        spectral_balance_ratios,
+        loudness_ratios
+    ):
+        """(B, 258, 1) global conditioning (generator.py:49-70)."""
+        lib = _lib.lib()
+        speakers = speakers.to(torch.long).contiguous()
+        batch = speakers.shape[0]
+        device = speakers.device
+        sbr = spectral_balance_ratios.to(
+            device=device, dtype=torch.float32).contiguous()
+        lr = loudness_ratios.to(device=device, dtype=torch.float32).contiguous()
+        if sbr.shape != (batch,) or lr.shape != (batch,):
+            raise ValueError('ratios must have shape (B,)')
+        table = self.speaker_embedding.weight.detach().to(
+            torch.float32).contiguous()
+        channels = table.shape[1]
+        out = torch.empty(batch, channels + 2, 1, device=device)
+        with torch.cuda.device(device):
+            _lib.check(lib.pm_prepare_global_features(
+                _lib.ptr(speakers, torch.long), _lib.ptr(sbr), _lib.ptr(lr),
+                _lib.ptr(table), _lib.ptr(out), batch, channels,
+                _lib.stream()))
+        return out
+
+    def remove_weight_norm(self):
+        self.model.remove_weight_norm()

@@ -1,0 +1,344 @@
+"""Speech synthesis from features, on the MI355X HIP engine.
+
+API of `promonet.synthesize` (promonet/synthesize/core.py): identical names,
+positional order, defaults and return conventions, plus a batched entry
+point the reference lacks (`from_features_batched`).
+"""
+import contextlib
+import os
+import time
+from pathlib import Path
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+import promonet_amd
+
+
+###############################################################################
+# Timers (the two torchutil.time contexts of synthesize/core.py:222,250)
+###############################################################################
+
+
+class timer:
+    """Wall-clock accumulators keyed like the reference's torchutil timers
+    ('load', 'generate'); read by `timer.results()` (evaluate/core.py:125)."""
+    seconds = {}
+
+    @classmethod
+    @contextlib.contextmanager
+    def context(cls, name):
+        start = time.perf_counter()
+        try:
+            yield
+        finally:
+            cls.seconds[name] = (
+                cls.seconds.get(name, 0.) + time.perf_counter() - start)
+
+    @classmethod
+    def reset(cls):
+        cls.seconds.clear()
+
+    @classmethod
+    def results(cls):
+        return dict(cls.seconds)
+
+
+###############################################################################
+# Editing API
+###############################################################################
+
+
+def from_features(
+    loudness: torch.Tensor,
+    pitch: torch.Tensor,
+    periodicity: torch.Tensor,
+    ppg: torch.Tensor,
+    speaker: Union[int, torch.Tensor] = 0,
+    spectral_balance_ratio: float = 1.,
+    loudness_ratio: float = 1.,
+    checkpoint: Optional[Union[str, os.PathLike]] = None,
+    gpu: Optional[int] = None
+) -> torch.Tensor:
+    """Perform speech synthesis (synthesize/core.py:18-59)
+
+    Args:
+        loudness: The loudness contour
+        pitch: The pitch contour
+        periodicity: The periodicity contour
+        ppg: The phonetic posteriorgram
+        speaker: The speaker index
+        spectral_balance_ratio: > 1 for Alvin and the Chipmunks; < 1 for Patrick Star
+        loudness_ratio: > 1 for louder; < 1 for quieter
+        checkpoint: The generator checkpoint
+        gpu: The GPU index (required: there is no CPU path)
+
+    Returns
+        generated: The generated speech, (1, samples) float32 - item 0 of the
+            batch only, as in the reference (core.py:281)
+    """
+    device = _device(gpu, pitch)
+    if loudness.ndim == 2:
+        loudness = loudness[None]
+    return generate(
+        loudness.to(device),
+        pitch.to(device),
+        periodicity.to(device),
+        ppg.to(device),
+        speaker,
+        spectral_balance_ratio,
+        loudness_ratio,
+        checkpoint
+    ).to(torch.float32)
+
+
+def from_features_batched(
+    loudness: torch.Tensor,
+    pitch: torch.Tensor,
+    periodicity: torch.Tensor,
+    ppg: torch.Tensor,
+    speakers: Union[int, torch.Tensor, List[int]] = 0,
+    spectral_balance_ratios: Union[float, torch.Tensor] = 1.,
+    loudness_ratios: Union[float, torch.Tensor] = 1.,
+    checkpoint: Optional[Union[str, os.PathLike]] = None,
+    gpu: Optional[int] = None
+) -> torch.Tensor:
+    """Batched synthesis: (B, 8|513, T), (B, T), (B, T), (B, 40, T) ->
+    (B, 1, 256 T). Per-utterance speakers and ratios; not in the reference,
+    whose public API returns utterance 0 only."""
+    device = _device(gpu, pitch)
+    batch = pitch.shape[0]
+
+    def per_item(value, dtype):
+        if isinstance(value, torch.Tensor):
+            return value.to(device=device, dtype=dtype).reshape(-1).expand(
+                batch).contiguous()
+        if isinstance(value, (list, tuple)):
+            return torch.tensor(value, dtype=dtype, device=device)
+        return torch.full((batch,), value, dtype=dtype, device=device)
+
+    model = _cached_model(checkpoint, device)
+    with timer.context('generate'), torch.inference_mode():
+        return model(
+            loudness.to(device), pitch.to(device), periodicity.to(device),
+            ppg.to(device), per_item(speakers, torch.long),
+            per_item(spectral_balance_ratios, torch.float),
+            per_item(loudness_ratios, torch.float),
+            model.default_previous_samples)
+
+
+def from_file(
+    loudness_file: Union[str, os.PathLike],
+    pitch_file: Union[str, os.PathLike],
+    periodicity_file: Union[str, os.PathLike],
+    ppg_file: Union[str, os.PathLike],
+    speaker: Union[int, torch.Tensor, Path, str] = 0,
+    spectral_balance_ratio: float = 1.,
+    loudness_ratio: float = 1.,
+    checkpoint: Optional[Union[str, os.PathLike]] = None,
+    gpu: Optional[int] = None
+) -> torch.Tensor:
+    """Perform speech synthesis from features on disk (core.py:62-111)"""
+    device = _device(gpu)
+    loudness = torch.load(loudness_file)
+    pitch = torch.load(pitch_file)
+    periodicity = torch.load(periodicity_file)
+    ppg = promonet_amd.load.ppg(
+        ppg_file, resample_length=pitch.shape[-1])[None]
+    return from_features(
+        loudness.to(device),
+        pitch.to(device),
+        periodicity.to(device),
+        ppg.to(device),
+        speaker,
+        spectral_balance_ratio,
+        loudness_ratio,
+        checkpoint,
+        gpu)
+
+
+def from_file_to_file(
+    loudness_file: Union[str, os.PathLike],
+    pitch_file: Union[str, os.PathLike],
+    periodicity_file: Union[str, os.PathLike],
+    ppg_file: Union[str, os.PathLike],
+    output_file: Union[str, os.PathLike],
+    speaker: Union[int, torch.Tensor, Path, str] = 0,
+    spectral_balance_ratio: float = 1.,
+    loudness_ratio: float = 1.,
+    checkpoint: Optional[Union[str, os.PathLike]] = None,
+    gpu: Optional[int] = None
+) -> None:
+    """Perform speech synthesis from features on disk and save
+    (core.py:114-155)"""
+    generated = from_file(
+        loudness_file,
+        pitch_file,
+        periodicity_file,
+        ppg_file,
+        speaker,
+        spectral_balance_ratio,
+        loudness_ratio,
+        checkpoint,
+        gpu
+    ).to('cpu')
+    output_file = Path(output_file)
+    output_file.parent.mkdir(exist_ok=True, parents=True)
+    save_audio(output_file, generated)
+
+
+def from_files_to_files(
+    loudness_files: List[Union[str, os.PathLike]],
+    pitch_files: List[Union[str, os.PathLike]],
+    periodicity_files: List[Union[str, os.PathLike]],
+    ppg_files: List[Union[str, os.PathLike]],
+    output_files: List[Union[str, os.PathLike]],
+    speakers: Optional[Union[List[int], torch.Tensor, Path, str]] = None,
+    spectral_balance_ratio: float = 1.,
+    loudness_ratio: float = 1.,
+    checkpoint: Optional[Union[str, os.PathLike]] = None,
+    gpu: Optional[int] = None
+) -> None:
+    """Perform batched speech synthesis from features on disk and save
+    (core.py:158-201; a sequential loop, as in the reference)"""
+    if speakers is None:
+        speakers = [0] * len(pitch_files)
+    iterator = zip(
+        loudness_files,
+        pitch_files,
+        periodicity_files,
+        ppg_files,
+        output_files,
+        speakers)
+    for item in iterator:
+        from_file_to_file(
+            *item,
+            spectral_balance_ratio=spectral_balance_ratio,
+            loudness_ratio=loudness_ratio,
+            checkpoint=checkpoint,
+            gpu=gpu)
+
+
+###############################################################################
+# Pipeline
+###############################################################################
+
+
+def generate(
+    loudness,
+    pitch,
+    periodicity,
+    ppg,
+    speaker=0,
+    spectral_balance_ratio: float = 1.,
+    loudness_ratio: float = 1.,
+    checkpoint=None
+) -> torch.Tensor:
+    """Generate speech from phoneme and prosody features (core.py:209-281)"""
+    device = pitch.device
+    model = _cached_model(checkpoint, device)
+
+    with timer.context('generate'):
+        speakers = torch.full(
+            (1,), speaker, dtype=torch.long, device=device)
+        spectral_balance_ratio = torch.tensor(
+            [spectral_balance_ratio], dtype=torch.float, device=device)
+        loudness_ratio = torch.tensor(
+            [loudness_ratio], dtype=torch.float, device=device)
+        batch = pitch.shape[0]
+        if batch > 1:
+            # The reference broadcasts one speaker over the batch through the
+            # (1, 512, 1) speaker-conv output (hifigan.py:68)
+            speakers = speakers.expand(batch).contiguous()
+            spectral_balance_ratio = \
+                spectral_balance_ratio.expand(batch).contiguous()
+            loudness_ratio = loudness_ratio.expand(batch).contiguous()
+        with torch.inference_mode():
+            return model(
+                loudness,
+                pitch,
+                periodicity,
+                ppg,
+                speakers,
+                spectral_balance_ratio,
+                loudness_ratio,
+                model.default_previous_samples
+            )[0]
+
+
+###############################################################################
+# Utilities
+###############################################################################
+
+
+def _device(gpu, like=None):
+    if gpu is None:
+        if like is not None and like.is_cuda:
+            return like.device
+        raise RuntimeError(
+            'promonet_amd.synthesize runs on an AMD GPU only: pass gpu=<index> '
+            '(the reference falls back to CPU PyTorch; this package does not)')
+    return torch.device(f'cuda:{gpu}')
+
+
+def _cached_model(checkpoint, device):
+    """Model cache on function attributes (core.py:225-248). Unlike the
+    reference, a `checkpoint=None` call does not reload on every call (the
+    reference compares the downloaded path with None, core.py:227,247)."""
+    with timer.context('load'):
+        if (
+            not hasattr(generate, 'model') or
+            generate.checkpoint != checkpoint or
+            generate.device != device
+        ):
+            model = promonet_amd.model.Generator()
+            file = checkpoint
+            if file is None:
+                import huggingface_hub
+                file = huggingface_hub.hf_hub_download(
+                    'maxrmorrison/promonet',
+                    f'generator-00{promonet_amd.STEPS}.pt')
+            else:
+                file = Path(file)
+                if file.is_dir():
+                    files = sorted(file.glob('generator-*.pt'))
+                    if not files:
+                        raise FileNotFoundError(
+                            f'no generator-*.pt in {file}')
+                    file = files[-1]
+            load_checkpoint(file, model)
+            generate.model = model.to(device).eval()
+            generate.checkpoint = checkpoint
+            generate.device = device
+    return generate.model
+
+
+def load_checkpoint(file, model):
+    """`torchutil.checkpoint.load(file, model)`: a torch.save'd dict with the
+    module state under 'model' (a bare state dict is accepted too)."""
+    state = torch.load(file, map_location='cpu')
+    if isinstance(state, dict) and 'model' in state and \
+            isinstance(state['model'], dict):
+        state = state['model']
+    model.load_state_dict(state)
+    return model
+
+
+def set_model(model, device=None):
+    """Install an already constructed Generator as the cached model (tests,
+    benchmarks, random-init runs without a checkpoint file)."""
+    if device is None:
+        device = next(model.parameters()).device
+    generate.model = model.to(device).eval()
+    generate.checkpoint = None
+    generate.device = torch.device(device)
+
+
+def save_audio(file, audio):
+    """32-bit float wav, as torchaudio.save writes a float tensor
+    (core.py:155)."""
+    import scipy.io.wavfile
+    scipy.io.wavfile.write(
+        str(file), promonet_amd.SAMPLE_RATE,
+        audio.detach().cpu().to(torch.float32).numpy().T.astype(np.float32))

@@ -1,0 +1,171 @@
+"""GPU parity, per kernel: HIP path (through the C ABI) vs the CPU oracle on
+the same seeded inputs. Tolerances: fp32 operand mode is exact-fp32 MFMA
+(only the summation order differs from ATen) -> 2e-5 relative to the output
+scale; f16 operands (fp32 accumulate) -> 2e-3 relative per layer."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import restatement as oracle
+from util import from_cl, max_abs, pad32, rel_err, to_cl
+
+pytestmark = pytest.mark.gpu
+
+TOL = {'fp32': 2e-5, 'f16': 2e-3, 'bf16': 1.5e-2}
+
+
+def lib():
+    from promonet_amd import _lib
+    return _lib
+
+
+def workspace(device, c_in, c_out, k):
+    size = lib().lib().pm_op_workspace_bytes(c_in, c_out, k)
+    return torch.empty(size, dtype=torch.uint8, device=device)
+
+
+def block_iteration_oracle(x, w1, b1, w2, b2, k, d):
+    xt = F.leaky_relu(x, .1)
+    xt = F.conv1d(xt, w1, b1, padding=oracle.get_padding(k, d), dilation=d)
+    xt = F.leaky_relu(xt, .1)
+    xt = F.conv1d(xt, w2, b2, padding=oracle.get_padding(k, 1))
+    return xt + x
+
+
+def run_block_iteration(
+    device, dtype, x, w1, b1, w2, b2, k, d, mode=0, scale=1., out_init=None
+):
+    _lib = lib()
+    b, c, l = x.shape
+    x_cl = to_cl(x).to(device)
+    out = torch.zeros_like(x_cl) if out_init is None \
+        else to_cl(out_init).to(device)
+    ws = workspace(device, c, c, k)
+    tensors = [t.to(device).contiguous() for t in (w1, b1, w2, b2)]
+    _lib.check(_lib.lib().pm_block_iteration_cl(
+        _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out),
+        *[_lib.ptr(t) for t in tensors], b, l, c, k, d, mode, scale,
+        ws.data_ptr(), ws.numel(), _lib.stream()))
+    torch.cuda.synchronize()
+    padded = out[:, :, c:]
+    assert padded.numel() == 0 or padded.abs().max().item() == 0.
+    return from_cl(out, c).cpu()
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
+@pytest.mark.parametrize('channels', [32, 64, 128, 256])
+@pytest.mark.parametrize('kernel_size', [3, 7, 11])
+def test_block_iteration(device, dtype, channels, kernel_size):
+    gen = torch.Generator().manual_seed(channels * 100 + kernel_size)
+    for d, length in ((1, 301), (3, 257), (5, 130)):
+        x = torch.randn(2, channels, length, generator=gen)
+        std = 1. / (channels * kernel_size) ** .5
+        w1 = torch.randn(channels, channels, kernel_size, generator=gen) * std
+        w2 = torch.randn(channels, channels, kernel_size, generator=gen) * std
+        b1 = torch.randn(channels, generator=gen) * .1
+        b2 = torch.randn(channels, generator=gen) * .1
+        want = block_iteration_oracle(x, w1, b1, w2, b2, kernel_size, d)
+        got = run_block_iteration(
+            device, dtype, x, w1, b1, w2, b2, kernel_size, d)
+        assert rel_err(got, want) < TOL[dtype], (d, length)
+
+
+@pytest.mark.parametrize('channels', [4, 8, 16, 48])
+def test_block_iteration_padded_channels(device, channels):
+    gen = torch.Generator().manual_seed(channels)
+    x = torch.randn(1, channels, 97, generator=gen)
+    w1 = torch.randn(channels, channels, 7, generator=gen) * .2
+    w2 = torch.randn(channels, channels, 7, generator=gen) * .2
+    b1 = torch.randn(channels, generator=gen)
+    b2 = torch.randn(channels, generator=gen)
+    want = block_iteration_oracle(x, w1, b1, w2, b2, 7, 3)
+    got = run_block_iteration(device, 'fp32', x, w1, b1, w2, b2, 7, 3)
+    assert rel_err(got, want) < TOL['fp32']
+
+
+def test_block_iteration_short_and_modes(device):
+    """Sequences shorter than the halo, one-sample sequences, and the MRF
+    accumulate epilogues (hifigan.py:141-145)."""
+    gen = torch.Generator().manual_seed(3)
+    c, k = 32, 11
+    w1 = torch.randn(c, c, k, generator=gen) * .05
+    w2 = torch.randn(c, c, k, generator=gen) * .05
+    b1 = torch.randn(c, generator=gen) * .1
+    b2 = torch.randn(c, generator=gen) * .1
+    for length in (1, 2, 9, 31, 118, 119, 236):
+        x = torch.randn(3, c, length, generator=gen)
+        want = block_iteration_oracle(x, w1, b1, w2, b2, k, 5)
+        got = run_block_iteration(device, 'fp32', x, w1, b1, w2, b2, k, 5)
+        assert rel_err(got, want) < TOL['fp32'], length
+    x = torch.randn(2, c, 200, generator=gen)
+    prev = torch.randn(2, c, 200, generator=gen)
+    want = block_iteration_oracle(x, w1, b1, w2, b2, k, 1)
+    got = run_block_iteration(
+        device, 'fp32', x, w1, b1, w2, b2, k, 1, mode=1, scale=1 / 3)
+    assert rel_err(got, want / 3) < TOL['fp32']
+    got = run_block_iteration(
+        device, 'fp32', x, w1, b1, w2, b2, k, 1, mode=2, scale=1 / 3,
+        out_init=prev)
+    assert rel_err(got, prev + want / 3) < TOL['fp32']
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'f16'])
+@pytest.mark.parametrize(
+    'c_in,c_out,rate',
+    [(512, 256, 8), (256, 128, 8), (128, 64, 2), (64, 32, 2), (64, 32, 8),
+     (32, 16, 2), (16, 8, 4)])
+def test_conv_transpose(device, dtype, c_in, c_out, rate):
+    _lib = lib()
+    gen = torch.Generator().manual_seed(c_in + rate)
+    k = 2 * rate
+    for length in (1, 5, 130):
+        x = torch.randn(2, c_in, length, generator=gen)
+        w = torch.randn(c_in, c_out, k, generator=gen) / (c_in * 2) ** .5
+        bias = torch.randn(c_out, generator=gen) * .1
+        want = F.conv_transpose1d(
+            F.leaky_relu(x, .1), w, bias, stride=rate,
+            padding=(k - rate) // 2)
+        x_cl = to_cl(x).to(device)
+        out = torch.zeros(
+            2, length * rate, pad32(c_out), device=device)
+        ws = workspace(device, c_in, c_out, k)
+        wd, bd = w.to(device), bias.to(device)
+        _lib.check(_lib.lib().pm_conv_transpose_cl(
+            _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out), _lib.ptr(wd),
+            _lib.ptr(bd), 2, length, c_in, c_out, rate, 1, ws.data_ptr(),
+            ws.numel(), _lib.stream()))
+        torch.cuda.synchronize()
+        assert rel_err(from_cl(out, c_out), want) < TOL[dtype], length
+
+
+def test_out_conv_tanh(device):
+    _lib = lib()
+    gen = torch.Generator().manual_seed(1)
+    for c, length in ((32, 1000), (8, 77), (32, 1)):
+        x = torch.randn(2, c, length, generator=gen)
+        w = torch.randn(1, c, 7, generator=gen) * .2
+        want = torch.tanh(F.conv1d(F.leaky_relu(x, .1), w, None, padding=3))
+        x_cl, wd = to_cl(x).to(device), w.to(device)
+        out = torch.empty(2, length, device=device)
+        _lib.check(_lib.lib().pm_out_conv_tanh(
+            _lib.ptr(x_cl), _lib.ptr(wd), _lib.ptr(out), 2, length, c,
+            _lib.stream()))
+        torch.cuda.synchronize()
+        assert max_abs(out[:, None], want) < 1e-5
+
+
+def test_fold_weight_norm(device):
+    _lib = lib()
+    gen = torch.Generator().manual_seed(2)
+    v = torch.randn(96, 32, 11, generator=gen) * .01
+    g = torch.rand(96, 1, 1, generator=gen) + .5
+    want = oracle.fold_weight_norm(g, v)
+    gd, vd = g.to(device), v.to(device)
+    out = torch.empty_like(vd)
+    _lib.check(_lib.lib().pm_fold_weight_norm(
+        _lib.ptr(gd), _lib.ptr(vd), _lib.ptr(out), 96, 32 * 11,
+        _lib.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(out, want) < 1e-6
