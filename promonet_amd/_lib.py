@@ -112,6 +112,13 @@ def ptr(tensor, dtype=torch.float32):
     return tensor.data_ptr()
 
 
+def require_gpu(tensor):
+    if not tensor.is_cuda:
+        raise RuntimeError(
+            'promonet_amd runs on an AMD GPU only (tensor is on '
+            f'{tensor.device}); there is no CPU fallback')
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 

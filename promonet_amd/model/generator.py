@@ -72,6 +72,7 @@ class Generator(torch.nn.Module):
 
     def _features(self, loudness, pitch, periodicity, ppg, channels_last):
         lib = _lib.lib()
+        _lib.require_gpu(pitch)
         if loudness.ndim == 2:
             loudness = loudness[None]
         loudness = loudness.to(torch.float32).contiguous()
@@ -119,6 +120,7 @@ class Generator(torch.nn.Module):
     ):
         """(B, 258, 1) global conditioning (generator.py:49-70)."""
         lib = _lib.lib()
+        _lib.require_gpu(speakers)
         speakers = speakers.to(torch.long).contiguous()
         batch = speakers.shape[0]
         device = speakers.device

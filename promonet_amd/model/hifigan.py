@@ -183,6 +183,7 @@ class HiFiGAN(torch.nn.Module):
         return self._run(x_cl, g, channels_last=True)
 
     def _run(self, x, g, channels_last):
+        _lib.require_gpu(x)
         engine = self.engine()
         lib = _lib.lib()
         x = x.to(torch.float32).contiguous()

@@ -18,6 +18,7 @@ def from_audio(audio, bands=1):
     own max - 80 dB floor, as separate reference calls would.
     """
     lib = _lib.lib()
+    _lib.require_gpu(audio)
     flat = audio.to(torch.float32).contiguous()
     batch, samples = flat.shape
     frames = samples // promonet_amd.HOPSIZE

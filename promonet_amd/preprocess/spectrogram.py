@@ -26,6 +26,7 @@ def from_audio(
         log_dynamic_range_compression_threshold = \
             promonet_amd.LOG_DYNAMIC_RANGE_COMPRESSION_THRESHOLD
     lib = _lib.lib()
+    _lib.require_gpu(audio)
     flat = audio.squeeze(1) if audio.ndim == 3 else audio
     flat = flat.to(torch.float32).contiguous()
     batch, samples = flat.shape
@@ -126,6 +127,7 @@ def linear_to_mel(spectrogram, log_dynamic_range_compression_threshold=None):
     The basis is cached per device (the reference rebuilds it on every call
     through a misnamed cache attribute, :117 vs :124)."""
     lib = _lib.lib()
+    _lib.require_gpu(spectrogram)
     squeeze = spectrogram.ndim == 2
     spec = (spectrogram[None] if squeeze else spectrogram).to(
         torch.float32).contiguous()

@@ -1,0 +1,111 @@
+"""CPU: the N > 1 path (batch sharding, weight broadcast, audio all-gather)
+over gloo with world_size 2. The synthesis function is a stand-in (the HIP
+engine needs a GPU); the collectives and the shard arithmetic are the code
+that runs over RCCL on the MI355X node."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import promonet_amd
+from promonet_amd import distributed
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def stand_in(loudness, pitch, periodicity, ppg, speakers, sbr, lr):
+    """Deterministic per-utterance 'audio' (B, 1, 256 T)."""
+    frame = pitch * sbr[:, None] + periodicity + ppg.sum(1) + \
+        loudness.mean(1) * lr[:, None] + speakers[:, None]
+    return frame.repeat_interleave(256, dim=-1)[:, None]
+
+
+def worker(rank, world, port, total, results):
+    os.environ.update(
+        RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+        MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    got_rank, got_world, device = distributed.init('gloo')
+    assert (got_rank, got_world) == (rank, world) and device.type == 'cpu'
+
+    # weight broadcast: every rank ends with rank 0's tensors
+    torch.manual_seed(rank)
+    model = torch.nn.Sequential(
+        torch.nn.Conv1d(3, 5, 3), torch.nn.Embedding(7, 4))
+    model.register_buffer('edges', torch.rand(6))
+    distributed.broadcast_model(model)
+    torch.manual_seed(0)
+    want = torch.nn.Sequential(
+        torch.nn.Conv1d(3, 5, 3), torch.nn.Embedding(7, 4))
+    want.register_buffer('edges', torch.rand(6))
+    for a, b in zip(model.state_dict().values(), want.state_dict().values()):
+        assert torch.equal(a, b)
+
+    # sharded synthesis + all-gather (uneven shards when total % world != 0)
+    gen = torch.Generator().manual_seed(5)
+    frames = 9
+    inputs = (
+        torch.rand(total, 8, frames, generator=gen),
+        torch.rand(total, frames, generator=gen),
+        torch.rand(total, frames, generator=gen),
+        torch.rand(total, 40, frames, generator=gen),
+        torch.arange(total), torch.rand(total, generator=gen),
+        torch.rand(total, generator=gen))
+    gathered = distributed.synthesize_sharded(stand_in, *inputs)
+    assert gathered.shape == (total, 1, frames * 256)
+    assert torch.equal(gathered, stand_in(*inputs))
+    local = distributed.synthesize_sharded(stand_in, *inputs, gather=False)
+    start, end = distributed.shard_bounds(total, rank, world)
+    assert local.shape[0] == end - start
+    results.put((rank, start, end))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run(total):
+    context = mp.get_context('spawn')
+    results = context.Queue()
+    port = free_port()
+    processes = [
+        context.Process(target=worker, args=(rank, 2, port, total, results))
+        for rank in range(2)]
+    for process in processes:
+        process.start()
+    for process in processes:
+        process.join(120)
+        assert process.exitcode == 0
+    bounds = sorted(results.get(timeout=5) for _ in range(2))
+    assert bounds[0][1] == 0 and bounds[0][2] == bounds[1][1]
+    assert bounds[1][2] == total
+
+
+def test_world_size_2_even():
+    run(total=8)
+
+
+def test_world_size_2_uneven():
+    run(total=5)
+
+
+def test_shard_bounds_cover_the_batch():
+    for total in (1, 7, 32, 256, 257):
+        for world in (1, 2, 4, 8):
+            pieces = [distributed.shard_bounds(total, r, world)
+                      for r in range(world)]
+            assert pieces[0][0] == 0 and pieces[-1][1] == total
+            for (a, b), (c, d) in zip(pieces, pieces[1:]):
+                assert b == c
+            sizes = [b - a for a, b in pieces]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_is_a_no_op():
+    audio = torch.rand(3, 1, 512)
+    assert distributed.all_gather_audio(audio, 3) is audio
+    model = torch.nn.Linear(2, 2)
+    assert distributed.broadcast_model(model) is model

@@ -1,0 +1,176 @@
+"""CPU: host logic of the drop-in package and the C-ABI surface (no compute
+calls - there is no GPU here)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+import promonet_amd
+from promonet_amd import _lib
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / 'include' / 'promonet_hip.h').read_text()
+    declared = set(re.findall(r'\b(pm_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 25
+    library = _lib.lib()
+    for name in declared:
+        assert hasattr(library, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert library.pm_version() >= 100
+
+
+def make_config(**overrides):
+    config = _lib.HifiganConfig()
+    config.num_features, config.global_channels = 113, 258
+    config.initial_channels, config.num_stages = 512, 4
+    for i, (r, k) in enumerate(zip((8, 8, 2, 2), (16, 16, 4, 4))):
+        config.upsample_rates[i], config.upsample_kernel_sizes[i] = r, k
+    config.num_resblocks, config.num_dilations = 3, 3
+    for j, k in enumerate((3, 7, 11)):
+        config.resblock_kernel_sizes[j] = k
+        for n, d in enumerate((1, 3, 5)):
+            config.resblock_dilations[j][n] = d
+    config.compute_dtype = _lib.PM_F16
+    for key, value in overrides.items():
+        setattr(config, key, value)
+    return config
+
+
+def test_engine_create_validates_configuration():
+    """pm_hifigan_create is host-only: error codes + messages, no exceptions
+    across the boundary."""
+    library = _lib.lib()
+    handle = ctypes.c_void_p()
+    assert library.pm_hifigan_create(
+        ctypes.byref(make_config()), ctypes.byref(handle)) == 0
+    assert library.pm_hifigan_hopsize(handle) == 256
+    assert library.pm_hifigan_features_cl_channels(handle) == 128
+    size = library.pm_hifigan_workspace_bytes(handle, 32, 861)
+    # 4 rotating fp32 activation buffers of 32 x 861 x 8192 floats + features
+    assert 4 * 32 * 861 * 8192 * 4 <= size < 4 * 32 * 861 * 8192 * 4 + 2 ** 25
+    # forward before finalize / with null pointers is refused, not a crash
+    assert library.pm_hifigan_forward(
+        handle, None, None, 1, None, 1, 8, None, 0, None) == -1
+    assert library.pm_hifigan_finalize(handle, None) == -2
+    assert b'missing tensor' in library.pm_last_error()
+    assert library.pm_hifigan_destroy(handle) == 0
+
+    bad = make_config()
+    bad.resblock_kernel_sizes[1] = 5
+    assert library.pm_hifigan_create(
+        ctypes.byref(bad), ctypes.byref(handle)) == -1
+    assert b'kernel size 5' in library.pm_last_error()
+    bad = make_config()
+    bad.upsample_kernel_sizes[0] = 15
+    assert library.pm_hifigan_create(
+        ctypes.byref(bad), ctypes.byref(handle)) == -1
+    bad = make_config(compute_dtype=7)
+    assert library.pm_hifigan_create(
+        ctypes.byref(bad), ctypes.byref(handle)) == -1
+    bad = make_config()
+    bad.resblock_dilations[0][2] = 9
+    assert library.pm_hifigan_create(
+        ctypes.byref(bad), ctypes.byref(handle)) == -1
+    with pytest.raises(RuntimeError, match='libpromonet_hip error -1'):
+        _lib.check(-1)
+
+
+def test_constants_match_reference(golden_default):
+    for key, value in golden_default['constants'].items():
+        assert getattr(promonet_amd, key) == value, key
+
+
+def test_state_dict_is_the_reference_contract(golden_default):
+    """Same keys and shapes as the reference Generator.state_dict()."""
+    model = promonet_amd.model.Generator()
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert mine == golden_default['state_keys']
+    assert sum(p.numel() for p in model.parameters()) == 14_230_784
+    assert torch.equal(
+        model.pitch_distribution, golden_default['pitch_distribution'])
+    # weight-normed init: g == ||v|| so that w == v (hifigan.py:220-223)
+    state = model.state_dict()
+    v = state['model.model.1.model.2.model.2.convs1.1.weight_v']
+    g = state['model.model.1.model.2.model.2.convs1.1.weight_g']
+    assert torch.allclose(g, torch.linalg.vector_norm(v, dim=(1, 2), keepdim=True))
+    assert abs(v.std().item() - .01) < 1e-3
+
+
+def test_no_cpu_fallback():
+    import restatement as oracle
+    model = promonet_amd.model.Generator()
+    inputs = oracle.synthetic_inputs(1, 8)
+    with pytest.raises(RuntimeError, match='AMD GPU'):
+        model(*inputs, None)
+    with pytest.raises(RuntimeError, match='AMD GPU'):
+        promonet_amd.synthesize.from_features(*inputs[:4])
+    with pytest.raises(RuntimeError, match='AMD GPU'):
+        promonet_amd.preprocess.spectrogram.from_audio(torch.zeros(1, 4096))
+    with pytest.raises(RuntimeError, match='AMD GPU'):
+        promonet_amd.preprocess.from_audio(torch.zeros(1, 4096))
+
+
+def test_product_never_imports_the_oracle():
+    for file in (ROOT / 'promonet_amd').rglob('*.py'):
+        text = file.read_text()
+        assert 'restatement' not in text and 'import oracle' not in text, file
+
+
+def test_convert():
+    assert promonet_amd.convert.seconds_to_frames(2) == 172
+    assert promonet_amd.convert.seconds_to_frames(5) == 430
+    assert promonet_amd.convert.seconds_to_frames(10) == 861
+    assert promonet_amd.convert.samples_to_frames(220416) == 861
+    assert promonet_amd.convert.frames_to_samples(861) == 220416
+    assert promonet_amd.convert.db_to_ratio(10.) == 2.
+    assert abs(promonet_amd.convert.ratio_to_db(2.) - 10.) < 1e-12
+    bins = promonet_amd.convert.hz_to_bins(torch.tensor([1., 56., 9999.]))
+    assert bins.tolist() == [0, 1, 255]
+
+
+def test_configure_rederives_static_constants():
+    try:
+        promonet_amd.configure(LOUDNESS_BANDS=4)
+        assert promonet_amd.NUM_FEATURES == 109
+    finally:
+        promonet_amd.configure(LOUDNESS_BANDS=8)
+    assert promonet_amd.NUM_FEATURES == 113
+    with pytest.raises(ValueError):
+        promonet_amd.configure(NOT_A_PARAMETER=1)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """torchutil-style checkpoint ({'model': state_dict}) and a bare state
+    dict both load; keys are the reference's."""
+    model = promonet_amd.model.Generator()
+    file = tmp_path / 'generator-00000001.pt'
+    torch.save({'model': model.state_dict(), 'step': 1}, file)
+    other = promonet_amd.model.Generator()
+    promonet_amd.synthesize.load_checkpoint(file, other)
+    for (ka, va), (kb, vb) in zip(
+            model.state_dict().items(), other.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    torch.save(model.state_dict(), file)
+    promonet_amd.synthesize.load_checkpoint(file, other)
+
+
+def test_loudness_host_helpers():
+    import restatement as oracle
+    gen = torch.Generator().manual_seed(0)
+    loudness = torch.rand(2, 513, 7, generator=gen) * 80 - 100
+    got = promonet_amd.preprocess.loudness.band_average(loudness, 8)
+    assert torch.equal(got, oracle.band_average(loudness, 8))
+    assert torch.equal(
+        promonet_amd.preprocess.loudness.normalize(got), oracle.normalize(got))
+    import numpy as np
+    assert np.array_equal(
+        promonet_amd.preprocess.loudness.perceptual_weights(),
+        oracle.perceptual_weights())
+    assert torch.allclose(
+        promonet_amd.preprocess.spectrogram.mel_basis(), oracle.mel_basis(),
+        atol=1e-8)

@@ -1,0 +1,137 @@
+"""CPU: the oracle (oracle/restatement.py) against the golden vectors the
+REAL reference produced (oracle/make_golden.py, build container only)."""
+import pytest
+import torch
+
+import restatement as oracle
+from util import max_abs
+
+
+def test_small_config_reference_state(golden_small):
+    """Reference-constructed weights (weight_g / weight_v pairs), every stage."""
+    g = golden_small
+    with torch.inference_mode():
+        features = oracle.prepare_features(
+            *g['inputs'][:4], g['state']['pitch_distribution'],
+            g['state']['pitch_embedding.weight'], g['state']['ppg_threshold'])
+        glob = oracle.prepare_global_features(
+            *g['inputs'][4:7], g['state']['speaker_embedding.weight'])
+        audio = oracle.generator_forward(*g['inputs'], g['state'])
+    assert max_abs(features, g['features']) == 0.
+    assert max_abs(glob, g['global_features']) == 0.
+    assert audio.shape == g['audio'].shape == (2, 1, 24 * 256)
+    assert max_abs(audio, g['audio']) < 1e-6
+
+
+def test_default_config_seeded_weights(golden_default):
+    g = golden_default
+    state = oracle.random_state(seed=g['seed'])
+    assert torch.equal(state['pitch_distribution'][:0], g['pitch_distribution'][:0])
+    state['pitch_distribution'] = g['pitch_distribution'].clone()
+    for name in ('b2_t40', 'b1_t7'):
+        entry = g[name]
+        inputs = oracle.synthetic_inputs(
+            entry['batch'], entry['frames'], seed=g['input_seed'])
+        with torch.inference_mode():
+            audio = oracle.generator_forward(*inputs, state)
+        assert max_abs(audio, entry['audio']) < 1e-6, name
+
+
+def test_from_features_contract(golden_default):
+    """(1, 256 T) float32, utterance 0 only (synthesize/core.py:59, :281)."""
+    g = golden_default
+    entry = g['from_features']
+    state = oracle.random_state(seed=g['seed'])
+    state['pitch_distribution'] = g['pitch_distribution'].clone()
+    inputs = oracle.synthetic_inputs(1, entry['frames'], seed=entry['input_seed'])
+    audio = oracle.from_features(
+        inputs[0][0], inputs[1], inputs[2], inputs[3], state,
+        entry['speaker'], entry['spectral_balance_ratio'],
+        entry['loudness_ratio'])
+    assert audio.shape == (1, entry['frames'] * 256)
+    assert audio.dtype == torch.float32
+    assert max_abs(audio, entry['audio']) < 1e-6
+
+
+def test_prepare_features_golden(golden_default):
+    g = golden_default
+    entry = g['features']
+    state = oracle.random_state(seed=g['seed'])
+    inputs = oracle.synthetic_inputs(2, entry['frames'], seed=entry['input_seed'])
+    wide = oracle.synthetic_inputs(
+        2, entry['frames'], seed=entry['input_seed'], loudness_rows=513)[0]
+    args = (g['pitch_distribution'], state['pitch_embedding.weight'],
+            state['ppg_threshold'])
+    assert max_abs(
+        oracle.prepare_features(*inputs[:4], *args), entry['rows8']) < 1e-6
+    assert max_abs(
+        oracle.prepare_features(wide, *inputs[1:4], *args),
+        entry['rows513']) < 1e-6
+    assert entry['rows8'].shape == (2, 113, entry['frames'])
+    # channel layout [ppg 40 | pitch 64 | loudness 8 | periodicity 1]
+    assert torch.equal(entry['rows8'][:, 112], inputs[2])
+    assert max_abs(
+        entry['rows8'][:, 104:112], (inputs[0] + 100.) / 120.) < 1e-6
+    # sparsify keeps the top 6 of 40 and renormalises
+    ppg = entry['rows8'][:, :40]
+    assert ((ppg > 1e-6).sum(1) == 6).all()
+    assert max_abs(ppg.sum(1), torch.ones(2, entry['frames'])) < 1e-5
+
+
+def test_pitch_bin_edges(golden_default):
+    """searchsorted(right=False) semantics quoted in SURVEY.md 3.2."""
+    edges = golden_default['pitch_distribution']
+    hz = torch.tensor(
+        [[1., 50., 56., edges[-1].item(), 600., edges[0].item()]])
+    bins = oracle.pitch_bins(hz, edges)
+    assert bins.tolist() == [[0, 0, 1, 255, 255, 0]]
+    assert (edges[1:] >= edges[:-1]).all() and edges.shape == (256,)
+
+
+def test_spectrogram_golden(golden_default):
+    entry = golden_default['spectrogram']
+    for key in ('one', 'many'):
+        got = oracle.spectrogram(entry[key + '_input'])
+        assert got.shape == entry[key].shape
+        assert max_abs(got, entry[key]) < 1e-6
+        dft = oracle.spectrogram_dft(entry[key + '_input'])
+        assert max_abs(dft.reshape(entry[key].shape), entry[key]) < 2e-5
+
+
+def test_weight_norm_fold():
+    gen = torch.Generator().manual_seed(0)
+    conv = torch.nn.utils.weight_norm(torch.nn.Conv1d(6, 4, 3))
+    convt = torch.nn.utils.weight_norm(torch.nn.ConvTranspose1d(6, 4, 4, 2, 1))
+    for module in (conv, convt):
+        module.weight_g.data = torch.rand(
+            module.weight_g.shape, generator=gen) + .5
+        x = torch.randn(1, 6, 9, generator=gen)
+        want = module(x)
+        folded = oracle.fold_weight_norm(
+            module.weight_g.data, module.weight_v.data)
+        if module is conv:
+            got = torch.nn.functional.conv1d(x, folded, module.bias, padding=0)
+        else:
+            got = torch.nn.functional.conv_transpose1d(
+                x, folded, module.bias, stride=2, padding=1)
+        assert max_abs(got, want) < 1e-6
+
+
+def test_unpinned_third_party_sanity():
+    """librosa / ppgs restatements are parity-unpinned (packages absent);
+    these are the self-consistency checks of SURVEY.md appendix A."""
+    import numpy as np
+    weights = oracle.a_weighting(np.array([0., 21.5, 100., 1000., 10000.]))
+    assert weights[0] == -80.
+    assert abs(weights[3]) < 1e-2 and abs(weights[2] + 19.14) < 0.05
+    assert abs(weights[4] + 2.49) < 0.05
+    basis = oracle.mel_basis()
+    assert basis.shape == (80, 513) and (basis.sum(1) > 0).all()
+    assert abs(basis[0].max().item() - 0.02317) < 1e-4
+    gen = torch.Generator().manual_seed(1)
+    audio = torch.randn(1, 256 * 12, generator=gen) * .1
+    loud = oracle.loudness(audio, 8)
+    assert loud.shape == (8, 12) and (loud >= -100.).all()
+    full = oracle.loudness(audio, None)
+    assert full.shape == (513, 12)
+    assert max_abs(oracle.band_average(full, 8), loud) < 1e-5

@@ -1,0 +1,277 @@
+"""GPU parity of the whole hot path (through the Python drop-in API, which
+calls the C ABI) against the committed reference goldens and the CPU oracle.
+
+Gate (BASELINE.json north_star): max-abs <= 1e-4 vs the fp32 reference
+generator; the fp32-operand mode is held to 2e-6."""
+import pytest
+import torch
+
+import restatement as oracle
+from util import max_abs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GATE = {'fp32': 2e-6, 'f16': 1e-4}
+
+
+def make_model(state, dtype, device):
+    import promonet_amd
+    promonet_amd.configure(COMPUTE_DTYPE=dtype)
+    model = promonet_amd.model.Generator()
+    model.load_state_dict(state)
+    promonet_amd.configure(COMPUTE_DTYPE='f16')
+    return model.to(device).eval()
+
+
+@pytest.fixture(scope='module')
+def default_state(golden_default):
+    state = oracle.random_state(seed=golden_default['seed'])
+    state['pitch_distribution'] = golden_default['pitch_distribution'].clone()
+    return state
+
+
+def on(device, inputs):
+    return [t.to(device) for t in inputs]
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'f16'])
+def test_generator_matches_reference_golden(
+    device, golden_default, default_state, dtype
+):
+    """Default config: weights regenerated from the seed, audio computed by
+    the REAL reference at fixture time (oracle/make_golden.py)."""
+    model = make_model(default_state, dtype, device)
+    for name in ('b2_t40', 'b1_t7'):
+        entry = golden_default[name]
+        inputs = oracle.synthetic_inputs(
+            entry['batch'], entry['frames'], seed=golden_default['input_seed'])
+        with torch.inference_mode():
+            got = model(*on(device, inputs), None)
+        assert got.shape == entry['audio'].shape
+        error = max_abs(got, entry['audio'])
+        print(f'{dtype} {name}: max-abs {error:.3e}')
+        assert error < GATE[dtype]
+
+
+def test_generator_bf16_recorded(device, golden_default, default_state):
+    """bf16 operands miss the 1e-4 gate with margin to spare for f16 (see
+    DESIGN.md): the test documents the measured error and bounds it."""
+    model = make_model(default_state, 'bf16', device)
+    entry = golden_default['b2_t40']
+    inputs = oracle.synthetic_inputs(2, 40, seed=golden_default['input_seed'])
+    with torch.inference_mode():
+        got = model(*on(device, inputs), None)
+    error = max_abs(got, entry['audio'])
+    print(f'bf16 b2_t40: max-abs {error:.3e}')
+    assert error < 1e-3
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'f16'])
+def test_small_config_reference_weights(device, golden_small, dtype):
+    """Tiny config (64 initial channels -> 32/16/8/4, exercises channel
+    padding) with the reference-constructed state dict."""
+    import promonet_amd
+    promonet_amd.configure(
+        HIFIGAN_UPSAMPLE_INITIAL_SIZE=64, COMPUTE_DTYPE=dtype)
+    try:
+        model = promonet_amd.model.Generator()
+        model.load_state_dict(golden_small['state'])
+        model = model.to(device).eval()
+        with torch.inference_mode():
+            got = model(*on(device, golden_small['inputs']), None)
+            features = model.prepare_features(
+                *on(device, golden_small['inputs'][:4]))
+            global_features = model.prepare_global_features(
+                *on(device, golden_small['inputs'][4:7]))
+    finally:
+        promonet_amd.configure(
+            HIFIGAN_UPSAMPLE_INITIAL_SIZE=512, COMPUTE_DTYPE='f16')
+    assert max_abs(features, golden_small['features']) < 1e-6
+    assert max_abs(global_features, golden_small['global_features']) == 0.
+    error = max_abs(got, golden_small['audio'])
+    print(f'small {dtype}: max-abs {error:.3e}')
+    assert error < GATE[dtype]
+
+
+def test_prepare_features_golden(device, golden_default, default_state):
+    model = make_model(default_state, 'f16', device)
+    entry = golden_default['features']
+    inputs = oracle.synthetic_inputs(2, entry['frames'], seed=entry['input_seed'])
+    wide = oracle.synthetic_inputs(
+        2, entry['frames'], seed=entry['input_seed'], loudness_rows=513)[0]
+    with torch.inference_mode():
+        rows8 = model.prepare_features(*on(device, inputs[:4]))
+        rows513 = model.prepare_features(
+            wide.to(device), *on(device, inputs[1:4]))
+        glob = model.prepare_global_features(*on(device, inputs[4:7]))
+    # pitch-embedding channels are gathers: exact
+    assert max_abs(rows8[:, 40:104], entry['rows8'][:, 40:104]) == 0.
+    assert max_abs(rows8, entry['rows8']) < 1e-6
+    assert max_abs(rows513, entry['rows513']) < 1e-6
+    assert max_abs(glob, entry['global']) == 0.
+
+
+def test_prepare_features_edge_cases(device, default_state):
+    """Pitch outside [FMIN, FMAX], exactly on bin edges, ties in the PPG."""
+    model = make_model(default_state, 'f16', device)
+    frames = 300
+    inputs = list(oracle.synthetic_inputs(1, frames, seed=8))
+    edges = default_state['pitch_distribution']
+    pitch = torch.cat([
+        torch.tensor([0., 10., 49.9, 50., 550., 551., 1e4]),
+        edges[:100], edges[-5:], edges[100:105] + 1e-4])
+    inputs[1] = torch.cat([pitch, inputs[1][0, pitch.numel():]])[None]
+    inputs[3][0, :, 5] = 1. / 40           # all-equal PPG frame
+    inputs[3][0, :, 6] = 0.
+    inputs[3][0, 3, 6] = 1.                # one-hot PPG frame
+    want = oracle.prepare_features(
+        *inputs[:4], edges, default_state['pitch_embedding.weight'],
+        default_state['ppg_threshold'])
+    with torch.inference_mode():
+        got = model.prepare_features(*on(device, inputs[:4]))
+    assert max_abs(got[:, 40:104], want[:, 40:104]) == 0.
+    assert max_abs(got, want) < 1e-6
+
+
+def test_from_features_api(device, golden_default, default_state):
+    """promonet.synthesize.from_features signature and return convention:
+    (1, 256 T) float32, item 0 only (synthesize/core.py:18-59, :281)."""
+    import promonet_amd
+    entry = golden_default['from_features']
+    model = make_model(default_state, 'fp32', device)
+    promonet_amd.synthesize.set_model(model, device)
+    inputs = oracle.synthetic_inputs(1, entry['frames'], seed=entry['input_seed'])
+    got = promonet_amd.synthesize.from_features(
+        inputs[0][0], inputs[1], inputs[2], inputs[3],
+        speaker=entry['speaker'],
+        spectral_balance_ratio=entry['spectral_balance_ratio'],
+        loudness_ratio=entry['loudness_ratio'], gpu=0)
+    assert got.dtype == torch.float32
+    assert got.shape == entry['audio'].shape == (1, entry['frames'] * 256)
+    assert max_abs(got, entry['audio']) < GATE['fp32']
+    with pytest.raises(RuntimeError):
+        promonet_amd.synthesize.from_features(
+            inputs[0][0], inputs[1], inputs[2], inputs[3])     # no gpu
+
+
+def test_batched_matches_single_and_is_deterministic(device, default_state):
+    """Size-independent properties at a larger size than the oracle is
+    comfortable with: every utterance of a batch equals the same utterance
+    synthesised alone (no cross-utterance coupling, tiles never straddle
+    utterances), repeated runs are bit-identical."""
+    model = make_model(default_state, 'f16', device)
+    batch, frames = 6, 333
+    inputs = on(device, oracle.synthetic_inputs(batch, frames, seed=21))
+    with torch.inference_mode():
+        full = model(*inputs, None)
+        again = model(*inputs, None)
+        assert torch.equal(full, again)
+        for item in (0, 3, 5):
+            single = model(*[t[item:item + 1] for t in inputs], None)
+            assert torch.equal(single[0], full[item])
+    assert full.shape == (batch, 1, frames * 256)
+    assert torch.isfinite(full).all()
+
+
+def test_time_tiling_with_halo(device, default_state):
+    """Fully-convolutional property: synthesising frames
+    [a - 14, b + 14) and cropping reproduces the whole-utterance output."""
+    model = make_model(default_state, 'fp32', device)
+    frames, a, b, halo = 120, 40, 80, 14
+    inputs = on(device, oracle.synthetic_inputs(1, frames, seed=4))
+    with torch.inference_mode():
+        full = model(*inputs, None)
+        sliced = [
+            t[..., a - halo:b + halo] if t.ndim >= 2 and t.shape[-1] == frames
+            else t for t in inputs]
+        part = model(*sliced, None)
+    want = full[..., a * 256:b * 256]
+    got = part[..., halo * 256:(halo + b - a) * 256]
+    assert max_abs(got, want) < 2e-6
+
+
+def test_full_size_forward(device, default_state):
+    """BASELINE.json full size (batch 32 x 861 frames): runs, finite, bounded
+    by tanh, and utterance 7 equals its stand-alone synthesis (fp32 oracle at
+    this size would take minutes; the property is size independent)."""
+    model = make_model(default_state, 'f16', device)
+    inputs = on(device, oracle.synthetic_inputs(32, 861, seed=1234))
+    with torch.inference_mode():
+        full = model(*inputs, None)
+        single = model(*[t[7:8] for t in inputs], None)
+    assert full.shape == (32, 1, 220416)
+    assert torch.isfinite(full).all() and full.abs().max() <= 1.
+    assert torch.equal(single[0], full[7])
+    # checked slice against the oracle: first 2 s of utterance 7 computed on
+    # frames [0, 186) (halo 14) by the CPU restatement
+    short = [t[7:8, ..., :186] if t.ndim >= 2 else t[7:8] for t in
+             oracle.synthetic_inputs(32, 861, seed=1234)]
+    want = oracle.generator_forward(*short, default_state)[..., :172 * 256]
+    assert max_abs(full[7:8, :, :172 * 256], want) < GATE['f16']
+
+
+###############################################################################
+# Preprocessing
+###############################################################################
+
+
+def test_spectrogram_golden(device, golden_default):
+    import promonet_amd
+    entry = golden_default['spectrogram']
+    one = promonet_amd.preprocess.spectrogram.from_audio(
+        entry['one_input'].to(device))
+    many = promonet_amd.preprocess.spectrogram.from_audio(
+        entry['many_input'].to(device))
+    assert one.shape == (513, 20) and many.shape == (3, 513, 10)
+    for got, want in ((one, entry['one']), (many, entry['many'])):
+        diff = (got.cpu() - want).abs()
+        assert (diff <= 2e-5 + 1e-5 * want.abs()).all(), diff.max()
+
+
+def test_spectrogram_long_and_ragged(device):
+    """Lengths that are not hop multiples, minimum length, many frames."""
+    import promonet_amd
+    gen = torch.Generator().manual_seed(3)
+    for samples in (385, 1000, 256 * 300 + 17):
+        audio = torch.randn(2, 1, samples, generator=gen) * .1
+        want = oracle.spectrogram(audio)
+        got = promonet_amd.preprocess.spectrogram.from_audio(audio.to(device))
+        assert got.shape == want.shape
+        diff = (got.cpu() - want).abs()
+        assert (diff <= 2e-5 + 1e-5 * want.abs()).all(), (samples, diff.max())
+
+
+def test_mel(device):
+    import promonet_amd
+    gen = torch.Generator().manual_seed(5)
+    audio = torch.randn(2, 1, 256 * 40, generator=gen) * .1
+    want = oracle.spectrogram(audio, mels=True)
+    got = promonet_amd.preprocess.spectrogram.from_audio(
+        audio.to(device), mels=True)
+    assert got.shape == want.shape == (2, 80, 40)
+    assert max_abs(got, want) < 1e-4
+    basis = promonet_amd.preprocess.spectrogram.mel_basis()
+    assert max_abs(basis, oracle.mel_basis()) < 1e-7
+    clamped = promonet_amd.preprocess.spectrogram.from_audio(
+        audio.to(device), mels=True,
+        log_dynamic_range_compression_threshold=-1.)
+    assert max_abs(clamped, torch.clamp(want, min=-1.)) < 1e-4
+
+
+def test_loudness(device):
+    import promonet_amd
+    gen = torch.Generator().manual_seed(6)
+    audio = torch.randn(1, 256 * 50, generator=gen) * .1
+    audio[:, 256 * 20:256 * 30] *= 1e-5        # exercise the max - 80 dB floor
+    for bands in (8, 1, None):
+        want = oracle.loudness(audio, bands)
+        got = promonet_amd.preprocess.loudness.from_audio(
+            audio.to(device), bands)
+        assert got.shape == want.shape
+        assert max_abs(got, want) < 2e-3, bands          # dB
+    # batched: each utterance keeps its own floor
+    pair = torch.cat([audio, audio * .01])
+    got = promonet_amd.preprocess.loudness.from_audio(pair.to(device), 8)
+    for item in range(2):
+        want = oracle.loudness(pair[item:item + 1], 8)
+        assert max_abs(got[item], want) < 2e-3
