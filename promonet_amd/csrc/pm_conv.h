@@ -100,6 +100,10 @@ __device__ __forceinline__ void mma_taps(
                     abuf[cur ^ 1][g][mt] =
                         wptr[mt * w_mt_stride + (g0 + G + g) * 64];
         }
+        // Keep the prefetch where it is: without this fence the scheduler
+        // sinks every A load to just before its MFMA (one register set,
+        // s_waitcnt vmcnt(0) per pair of MFMAs = an L2 round trip each).
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int step = g0 + g;
@@ -115,6 +119,7 @@ __device__ __forceinline__ void mma_taps(
                 for (int nt = 0; nt < NTW; ++nt)
                     ET::mma(abuf[cur][g][mt], b[nt], acc[mt][nt]);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
