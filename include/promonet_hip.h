@@ -155,6 +155,15 @@ int pm_block_iteration_cl(int dtype, const float* x_cl, float* out_cl,
                           int channels, int kernel_size, int dilation,
                           int mode, float scale, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* A whole Block (hifigan.py:198-210), all `niter` <= 3 dilations fused in
+ * one kernel (channels <= 64); w1/b1/w2/b2 are HOST arrays of `niter` device
+ * pointers; workspace >= 3 * pm_op_workspace_bytes(c, c, k)               */
+int pm_block_cl(int dtype, const float* x_cl, float* out_cl,
+                const float* const* w1, const float* const* b1,
+                const float* const* w2, const float* const* b2,
+                const int* dilations, int niter, int batch, int length,
+                int channels, int kernel_size, int mode, float scale,
+                void* workspace, size_t workspace_bytes, void* stream);
 /* lrelu(optional) -> ConvTranspose1d(c_in, c_out, k = 2 r, stride r,
  * padding r / 2) (hifigan.py:97-106), channels-last: (B, L, c_in_pad) ->
  * (B, L * r, c_out_pad)                                                   */
@@ -167,6 +176,9 @@ int pm_conv_transpose_cl(int dtype, const float* x_cl, float* out_cl,
  * (B, L, c_pad) channels-last -> (B, L)                                   */
 int pm_out_conv_tanh(const float* x_cl, const float* w, float* out,
                      int batch, int length, int channels, void* stream);
+/* Debug instrumentation: per-workgroup phase timestamps (s_memtime) of the
+ * following fused-conv launches; buffer of 8 uint64 per workgroup or NULL  */
+int pm_debug_timeline(void* dev_buffer);
 /* torch.nn.utils.weight_norm fold: w = g * v / ||v||, rows x cols        */
 int pm_fold_weight_norm(const float* g, const float* v, float* w, int rows,
                         int cols, void* stream);

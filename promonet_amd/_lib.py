@@ -58,8 +58,10 @@ SIGNATURES = {
     'pm_prepare_global_features': (_I, [_P] * 5 + [_I, _I, _P]),
     'pm_op_workspace_bytes': (_S, [_I, _I, _I]),
     'pm_block_iteration_cl': (_I, [_I] + [_P] * 6 + [_I] * 6 + [_F, _P, _S, _P]),
+    'pm_block_cl': (_I, [_I, _P, _P] + [_P] * 5 + [_I] * 6 + [_F, _P, _S, _P]),
     'pm_conv_transpose_cl': (_I, [_I] + [_P] * 4 + [_I] * 6 + [_P, _S, _P]),
     'pm_out_conv_tanh': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'pm_debug_timeline': (_I, [_P]),
     'pm_fold_weight_norm': (_I, [_P, _P, _P, _I, _I, _P]),
     'pm_to_channels_last': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'pm_stft_scratch_bytes': (_S, [_I, _I]),

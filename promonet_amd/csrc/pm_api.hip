@@ -41,6 +41,8 @@ static int fail(int code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);          \
     } while (0)
 
+static unsigned long long* g_timeline = nullptr;   // pm_debug_timeline
+
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 static inline int esz(int dtype) { return dtype == PM_F32 ? 4 : 2; }
@@ -49,13 +51,37 @@ static inline int esz(int dtype) { return dtype == PM_F32 ? 4 : 2; }
 // dtype dispatch
 // ---------------------------------------------------------------------------
 static hipError_t launch_pair(
-    int dtype, int C, int K, const PairArgs& a, hipStream_t s) {
+    int dtype, int C, int K, const PairArgs& a0, hipStream_t s) {
+    PairArgs a = a0;
+    a.timeline = g_timeline;
     switch (dtype) {
         case PM_F32: return pm_launch_pair<ElemF32>(C, K, a, s);
         case PM_F16: return pm_launch_pair<ElemF16>(C, K, a, s);
         case PM_BF16: return pm_launch_pair<ElemBF16>(C, K, a, s);
     }
     return hipErrorInvalidValue;
+}
+
+static hipError_t launch_block3(
+    int dtype, int C, int K, const Block3Args& a0, hipStream_t s) {
+    Block3Args a = a0;
+    a.timeline = g_timeline;
+    switch (dtype) {
+        case PM_F32: return pm_launch_block3<ElemF32>(C, K, a, s);
+        case PM_F16: return pm_launch_block3<ElemF16>(C, K, a, s);
+        case PM_BF16: return pm_launch_block3<ElemBF16>(C, K, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// PM_FUSION=pair forces one kernel per Block iteration everywhere (A/B runs)
+static bool block3_enabled() {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("PM_FUSION");
+        enabled = (e && !strcmp(e, "pair")) ? 0 : 1;
+    }
+    return enabled == 1;
 }
 
 static hipError_t launch_single(
@@ -585,7 +611,31 @@ static int forward_impl(
         }
         L *= st.r;
         const int si = xi;   // stage input is dead after the upsampler
+        const bool fuse_block = block3_enabled() && st.cout_pad <= 64 &&
+                                h->cfg.num_dilations <= 3;
         for (int j = 0; j < h->cfg.num_resblocks; ++j) {
+            const int K = h->cfg.resblock_kernel_sizes[j];
+            if (fuse_block) {
+                // whole Block (all dilations) in one kernel: U -> S
+                Block3Args a = {};
+                a.x = buf[ui]; a.out = buf[si];
+                a.niter = h->cfg.num_dilations;
+                double flops = 0;
+                for (int n = 0; n < a.niter; ++n) {
+                    a.w1[n] = st.c1[j][n].w; a.b1[n] = st.c1[j][n].bias;
+                    a.w2[n] = st.c2[j][n].w; a.b2[n] = st.c2[j][n].bias;
+                    a.dil[n] = h->cfg.resblock_dilations[j][n];
+                    flops += 4.0 * st.cout * st.cout * K * B * L;
+                }
+                a.B = B; a.L = L; a.mode = j == 0 ? 1 : 2; a.scale = scale;
+                char label[64];
+                snprintf(label, sizeof(label), "block_c%d_k%d", st.cout, K);
+                PROF(h, s, label, flops,
+                     (double)B * L * st.cout * 4 * (a.mode == 2 ? 3 : 2), {
+                    HIP_TRY(launch_block3(h->dtype, st.cout_pad, K, a, s));
+                });
+                continue;
+            }
             const float* src = buf[ui];
             for (int n = 0; n < h->cfg.num_dilations; ++n) {
                 const bool last = n == h->cfg.num_dilations - 1;
@@ -598,7 +648,6 @@ static int forward_impl(
                 a.dilation = h->cfg.resblock_dilations[j][n];
                 a.mode = last ? (j == 0 ? 1 : 2) : 0;
                 a.scale = scale;
-                const int K = h->cfg.resblock_kernel_sizes[j];
                 char label[64];
                 snprintf(label, sizeof(label), "pair_c%d_k%d", st.cout, K);
                 PROF(h, s, label, 4.0 * st.cout * st.cout * K * B * L,
@@ -774,6 +823,54 @@ extern "C" int pm_block_iteration_cl(
     a.x = x; a.out = out; a.w1 = p1; a.w2 = p2; a.b1 = pb1; a.b2 = pb2;
     a.B = B; a.L = L; a.dilation = d; a.mode = mode; a.scale = scale;
     HIP_TRY(launch_pair(dtype, Cp, K, a, s));
+    return PM_OK;
+}
+
+// Debug: subsequent pair / whole-Block launches make wave 0 of workgroup i
+// write 8 shader-clock stamps to timeline[8 i ..] (NULL switches it off).
+extern "C" int pm_debug_timeline(void* dev_buffer) {
+    g_timeline = (unsigned long long*)dev_buffer;
+    return PM_OK;
+}
+
+extern "C" int pm_block_cl(
+    int dtype, const float* x, float* out, const float* const* w1,
+    const float* const* b1, const float* const* w2, const float* const* b2,
+    const int* dilations, int niter, int B, int L, int C, int K, int mode,
+    float scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !out || !w1 || !b1 || !w2 || !b2 || !dilations || !ws)
+        return fail(PM_EINVAL, "null argument");
+    const int Cp = pad32(C);
+    if (Cp > 64) return fail(PM_EINVAL, "channels %d unsupported (<= 64)", C);
+    if ((K != 3 && K != 7 && K != 11) || niter < 1 || niter > 3)
+        return fail(PM_EINVAL, "kernel %d / %d iterations unsupported", K, niter);
+    if (ws_bytes < 3 * pm_op_workspace_bytes(C, C, K))
+        return fail(PM_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ConvGeom g;
+    g.mode = 0; g.cout = g.cin = C; g.k = K; g.cout_pad = g.cin_pad = g.M = Cp;
+    g.kt = K; g.ch = Cp;
+    Block3Args a = {};
+    a.x = x; a.out = out; a.niter = niter; a.B = B; a.L = L; a.mode = mode;
+    a.scale = scale;
+    const size_t per = pm_op_workspace_bytes(C, C, K);
+    const size_t wsz = align256((size_t)Cp * Cp * K * 4);
+    for (int n = 0; n < niter; ++n) {
+        char* base = (char*)ws + n * per;
+        void* p1 = base; void* p2 = base + wsz;
+        float* pb1 = (float*)(base + 2 * wsz);
+        float* pb2 = pb1 + align256(Cp * 64 * 4) / 4;
+        HIP_TRY(pack_weights(dtype, g, w1[n], p1, s));
+        HIP_TRY(pack_weights(dtype, g, w2[n], p2, s));
+        HIP_TRY(pad_bias(b1[n], pb1, C, Cp, 1, s));
+        HIP_TRY(pad_bias(b2[n], pb2, C, Cp, 1, s));
+        a.w1[n] = p1; a.w2[n] = p2; a.b1[n] = pb1; a.b2[n] = pb2;
+        a.dil[n] = dilations[n];
+    }
+    hipError_t e = launch_block3(dtype, Cp, K, a, s);
+    if (e == hipErrorNotSupported)
+        return fail(PM_EINVAL, "no whole-Block kernel for this shape");
+    HIP_TRY(e);
     return PM_OK;
 }
 

@@ -74,21 +74,42 @@ struct ChunkStager {
 };
 
 // All taps x all k16-steps of one staged channel chunk for this wave's
-// MTW x NTW grid of 32x32 tiles. A fragments are double-buffered in
-// registers one group (G steps) ahead of the MFMAs that consume them.
-template <class ET, int KT, int KC, int MTW, int NTW, int G, int S>
-__device__ __forceinline__ void mma_taps(
-    floatx16 (&acc)[MTW][NTW], const char* bptr, const int tap_bytes,
+// MTW x NTW grid of 32x32 tiles, software pipelined in registers: A
+// fragments one group (G steps) ahead, B fragments one step ahead.
+// Load the first A group of a weight stream (issued early, e.g. before a
+// barrier, so its L2 latency is off the critical path of mma_taps()).
+template <class ET, int MTW, int G>
+__device__ __forceinline__ void load_a_group(
+    typename ET::frag_t (&dst)[G][MTW],
     const typename ET::frag_t* __restrict__ wptr, const int w_mt_stride) {
-    typedef typename ET::frag_t frag_t;
-    constexpr int NS = KT * KC;
-    static_assert(NS % G == 0, "group size must divide the step count");
-    frag_t abuf[2][G][MTW];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
-            abuf[0][g][mt] = wptr[mt * w_mt_stride + g * 64];
+            dst[g][mt] = wptr[mt * w_mt_stride + g * 64];
+}
+
+// `first` holds group 0 of this call's weight stream on entry (see
+// load_a_group); when `wnext` is non-null, group 0 of the NEXT call's stream
+// is fetched during the last group and returned in `first`.
+template <class ET, int KT, int KC, int MTW, int NTW, int G, int S>
+__device__ __forceinline__ void mma_taps(
+    floatx16 (&acc)[MTW][NTW], const char* bptr, const int tap_bytes,
+    const typename ET::frag_t* __restrict__ wptr, const int w_mt_stride,
+    typename ET::frag_t (&first)[G][MTW],
+    const typename ET::frag_t* __restrict__ wnext) {
+    typedef typename ET::frag_t frag_t;
+    constexpr int NS = KT * KC;
+    static_assert(NS % G == 0, "group size must divide the step count");
+    frag_t abuf[2][G][MTW];   // A (weights): one GROUP ahead, from L2
+    frag_t bbuf[2][NTW];      // B (activations): one STEP ahead, from LDS
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) abuf[0][g][mt] = first[g][mt];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+        bbuf[0][nt] = *reinterpret_cast<const frag_t*>(bptr + nt * 32 * S);
 #pragma unroll
     for (int g0 = 0; g0 < NS; g0 += G) {
         const int cur = (g0 / G) & 1;
@@ -97,31 +118,60 @@ __device__ __forceinline__ void mma_taps(
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
+#ifdef PM_ABLATE_A   // timing experiment only: no weight stream
+                    abuf[cur ^ 1][g][mt] = abuf[cur][g][mt];
+#else
                     abuf[cur ^ 1][g][mt] =
                         wptr[mt * w_mt_stride + (g0 + G + g) * 64];
+#endif
+        } else if (wnext) {
+            load_a_group<ET, MTW, G>(abuf[cur ^ 1], wnext, w_mt_stride);
         }
-        // Keep the prefetch where it is: without this fence the scheduler
-        // sinks every A load to just before its MFMA (one register set,
-        // s_waitcnt vmcnt(0) per pair of MFMAs = an L2 round trip each).
+        // The fences pin the software pipeline. Left alone, the scheduler
+        // sinks every load to just before its MFMA into ONE register set:
+        // s_waitcnt vmcnt(0) (an L2 round trip) per A fragment and
+        // ds_read -> lgkmcnt(0) -> MFMA (an LDS round trip) per MFMA.
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int step = g0 + g;
-            const int j = step / KC, kc = step % KC;
-            frag_t b[NTW];
+            const int cb = step & 1;
+            if (step + 1 < NS) {
+                const int j = (step + 1) / KC, kc = (step + 1) % KC;
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-                b[nt] = *reinterpret_cast<const frag_t*>(
-                    bptr + nt * 32 * S + j * tap_bytes + kc * 16 * ET::ESZ);
+                for (int nt = 0; nt < NTW; ++nt)
+#ifdef PM_ABLATE_B   // timing experiment only: no LDS operand stream
+                    bbuf[cb ^ 1][nt] = bbuf[cb][nt];
+#else
+                    bbuf[cb ^ 1][nt] = *reinterpret_cast<const frag_t*>(
+                        bptr + nt * 32 * S + j * tap_bytes +
+                        kc * 16 * ET::ESZ);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
-                    ET::mma(abuf[cur][g][mt], b[nt], acc[mt][nt]);
+                    ET::mma(abuf[cur][g][mt], bbuf[cb][nt], acc[mt][nt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
+    constexpr int LAST = ((NS / G) - 1) & 1;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) first[g][mt] = abuf[LAST ^ 1][g][mt];
 }
+
+// Debug instrumentation (pm_debug_timeline): wave 0 of every workgroup stamps
+// the shader clock at phase boundaries; costs one scalar branch when off.
+#define PM_STAMP(args, i)                                                    \
+    do {                                                                     \
+        if ((args).timeline && threadIdx.x == 0)                             \
+            (args).timeline[(size_t)blockIdx.x * 8 + (i)] =                  \
+                __builtin_amdgcn_s_memtime();                                \
+    } while (0)
 
 // ---------------------------------------------------------------------------
 // Fused Block iteration
@@ -139,6 +189,7 @@ struct PairArgs {
     int mode;            // 0: out = y; 1: out = y * scale; 2: out += y * scale
     float scale;
     int ntiles;          // tiles per utterance
+    unsigned long long* timeline;   // debug: 8 s_memtime stamps per block
 };
 
 template <int C, int K, int WN, int NTW>
@@ -206,16 +257,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     // ---------------- conv1: K-loop over staged channel chunks -------------
-    ChunkStager<ET, CH, NT, XR_MAX> stager;
-    stager.load(xb, C, 0, t_first, XR, L, tid);
-    stager.template store<true>(xbuf, XR, tid);
-    __syncthreads();
-
     const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1) +
                        (size_t)(wm * MTW) * (NCH * K * KC * 64) + lane;
     const frag_t* w2 = reinterpret_cast<const frag_t*>(a.w2) +
                        (size_t)(wm * MTW) * (NCH * K * KC * 64) + lane;
     constexpr int W_MT_STRIDE = NCH * K * KC * 64;
+    constexpr int W_CHUNK = K * KC * 64;
+    frag_t afirst[G][MTW];
+    PM_STAMP(a, 0);
+    load_a_group<ET, MTW, G>(afirst, w1, W_MT_STRIDE);
+
+    ChunkStager<ET, CH, NT, XR_MAX> stager;
+    stager.load(xb, C, 0, t_first, XR, L, tid);
+    stager.template store<true>(xbuf, XR, tid);
+    __syncthreads();
+    PM_STAMP(a, 1);
     const int lane_off_x =
         ((wn * NTW * 32) + ln) * SX + lh * 8 * ET::ESZ;
 
@@ -224,8 +280,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
         char* cur = xbuf + (NCH > 1 ? (c & 1) * XR * SX : 0);
         if (c + 1 < NCH) stager.load(xb, C, (c + 1) * CH, t_first, XR, L, tid);
         mma_taps<ET, K, KC, MTW, NTW, G, SX>(
-            acc, cur + lane_off_x, d * SX, w1 + (size_t)c * (K * KC * 64),
-            W_MT_STRIDE);
+            acc, cur + lane_off_x, d * SX, w1 + (size_t)c * W_CHUNK,
+            W_MT_STRIDE, afirst,
+            c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
         if (c + 1 < NCH) {
             char* nxt = xbuf + ((c + 1) & 1) * XR * SX;
             stager.template store<true>(nxt, XR, tid);
@@ -233,6 +290,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
         }
     }
 
+    PM_STAMP(a, 2);
     // ---------------- epilogue 1: bias, lrelu, zero-pad mask -> LDS --------
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
@@ -260,6 +318,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
         }
     }
     __syncthreads();
+    PM_STAMP(a, 3);
 
     // ---------------- conv2 (dilation 1) straight out of LDS ---------------
     const int lane_off_i = ((wn * NTW * 32) + ln) * SI + lh * 8 * ET::ESZ;
@@ -267,9 +326,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
     for (int c = 0; c < NCH; ++c) {
         mma_taps<ET, K, KC, MTW, NTW, G, SI>(
             acc, inter + lane_off_i + c * CH * ET::ESZ, SI,
-            w2 + (size_t)c * (K * KC * 64), W_MT_STRIDE);
+            w2 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
+            c + 1 < NCH ? w2 + (size_t)(c + 1) * W_CHUNK : nullptr);
     }
 
+    PM_STAMP(a, 4);
     // ---------------- epilogue 2: bias + residual (+ MRF accumulate) -------
     float* ob = a.out + (size_t)b * L * C;
 #pragma unroll
@@ -307,6 +368,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
             }
         }
     }
+    PM_STAMP(a, 5);
 }
 
 // ---------------------------------------------------------------------------
@@ -397,6 +459,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
     const int w_mt_stride = NCH * KT * KC * 64;
     const frag_t* w = reinterpret_cast<const frag_t*>(a.w) +
                       (size_t)(m0 / 32) * w_mt_stride + lane;
+    frag_t afirst[G][MTW];
+    load_a_group<ET, MTW, G>(afirst, w, w_mt_stride);
     const int lane_off_x =
         ((wn * NTW * 32) + ln + js) * SX + lh * 8 * ET::ESZ;
 
@@ -407,7 +471,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
             stager.load(xb, Cin, (c + 1) * CH, t_first, XR, L, tid);
         mma_taps<ET, KT, KC, MTW, NTW, G, SX>(
             acc, cur + lane_off_x, SX, w + (size_t)c * (KT * KC * 64),
-            w_mt_stride);
+            w_mt_stride, afirst,
+            c + 1 < NCH ? w + (size_t)(c + 1) * (KT * KC * 64) : nullptr);
         if (c + 1 < NCH) {
             char* nxt = smem + ((c + 1) & 1) * XR * SX;
             if (a.lrelu) stager.template store<true>(nxt, XR, tid);
@@ -489,4 +554,249 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
             atomicMax(a.maxbits + b, pm_float_order_bits(local_max));
     }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Whole `Block` fused (small channel counts, C <= 64): all 3 iterations of
+//   x <- x + conv2(lrelu(conv1(lrelu(x))))            hifigan.py:198-210
+// in one kernel. The fp32 trunk x lives in REGISTERS (MFMA C/D layout, each
+// wave owns a run of time columns x a 32-channel slab), LDS only holds the two
+// 16-bit MFMA B operands: `a` = lrelu(x) and `t` = lrelu(conv1). HBM traffic
+// per Block drops from 3 x (read + write) to one read (with a +-6 (k-1)
+// halo, recomputed) and one write.
+// ---------------------------------------------------------------------------
+
+struct Block3Args {
+    const float* x;
+    float* out;
+    const void* w1[3];
+    const void* w2[3];
+    const float* b1[3];
+    const float* b2[3];
+    int dil[3];
+    int niter;
+    int B, L;
+    int mode;            // 0: out = y; 1: out = y * scale; 2: out += y * scale
+    float scale;
+    int ntiles, halo, TL;
+    unsigned long long* timeline;   // debug: 8 s_memtime stamps per block
+};
+
+template <class ET, int C, int K, int WM, int WN, int NTW>
+__host__ __device__ constexpr int block3_smem_bytes() {
+    constexpr int NC = WN * NTW * 32;
+    constexpr int S = C * ET::ESZ + 16;
+    return (NC + 10 * ((K - 1) / 2)) * S + (NC + (K - 1)) * S;
+}
+
+template <class ET, int C, int K, int WM, int WN, int NTW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
+    Block3Args a) {
+    typedef typename ET::frag_t frag_t;
+    static_assert(C == 32 || C == 64, "block3 kernel is for C <= 64");
+    constexpr int KC = C / 16;
+    constexpr int MTW = (C / 32) / WM;     // M tiles per wave
+    constexpr int NC = WN * NTW * 32;      // columns held by the workgroup
+    constexpr int NT = WM * WN * 64;
+    constexpr int H2 = (K - 1) / 2;
+    constexpr int MA = 5 * H2;             // margin of `a` (max dilation 5)
+    constexpr int S = C * ET::ESZ + 16;
+    constexpr int ROWS_A = NC + 2 * MA;
+    constexpr int ROWS_T = NC + 2 * H2;
+    constexpr int G = (ET::ESZ == 4) ? 2 : KC;
+    constexpr int W_MT_STRIDE = K * KC * 64;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* abuf = smem;
+    char* tbuf = smem + ROWS_A * S;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m_first = wm * MTW * 32;     // this wave's first channel
+    const int ln = lane & 31, lh = lane >> 5;
+
+    const int wg = pm_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = wg % a.ntiles;
+    const int b = wg / a.ntiles;
+    const int L = a.L;
+    const int c_first = tile * a.TL - a.halo;   // time of column 0
+    const float* xb = a.x + (size_t)b * L * C;
+
+    // ---- zero the margins (they stand for neighbours' columns: only ever
+    // feed the recomputed halo, but must be finite) ------------------------
+    {
+        constexpr int QS = S / 16;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < 2 * MA * QS; i += NT) {
+            const int r = i / QS, q = i % QS;
+            const int row = r < MA ? r : NC + r;
+            *reinterpret_cast<float4*>(abuf + row * S + q * 16) = z;
+        }
+        for (int i = tid; i < 2 * H2 * QS; i += NT) {
+            const int r = i / QS, q = i % QS;
+            const int row = r < H2 ? r : NC + r;
+            *reinterpret_cast<float4*>(tbuf + row * S + q * 16) = z;
+        }
+    }
+    // ---- stage a = lrelu(x) (coalesced), zero outside the utterance ------
+    {
+        constexpr int Q = C / 4;
+        for (int i = tid; i < NC * Q; i += NT) {
+            const int col = i / Q, q = i % Q;
+            const int t = c_first + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < L)
+                v = *reinterpret_cast<const float4*>(
+                    xb + (size_t)t * C + q * 4);
+            v.x = pm_lrelu(v.x); v.y = pm_lrelu(v.y);
+            v.z = pm_lrelu(v.z); v.w = pm_lrelu(v.w);
+            ET::store4(abuf + (MA + col) * S + q * 4 * ET::ESZ, v);
+        }
+    }
+    // ---- trunk registers <- x in the MFMA C/D layout ----------------------
+    floatx16 trunk[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int t = c_first + (wn * NTW + nt) * 32 + ln;
+            const bool inside = t >= 0 && t < L;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inside)
+                    v = *reinterpret_cast<const float4*>(
+                        xb + (size_t)t * C + m_first + mt * 32 + 8 * g4 + 4 * lh);
+                trunk[mt][nt][4 * g4 + 0] = v.x;
+                trunk[mt][nt][4 * g4 + 1] = v.y;
+                trunk[mt][nt][4 * g4 + 2] = v.z;
+                trunk[mt][nt][4 * g4 + 3] = v.w;
+            }
+        }
+    __syncthreads();
+
+    const int col_off = (wn * NTW * 32 + ln) * S + lh * 8 * ET::ESZ;
+    floatx16 acc[MTW][NTW];
+    frag_t afirst[G][MTW];
+    load_a_group<ET, MTW, G>(
+        afirst, reinterpret_cast<const frag_t*>(a.w1[0]) +
+                    (size_t)(wm * MTW) * W_MT_STRIDE + lane, W_MT_STRIDE);
+
+#pragma unroll 1
+    for (int it = 0; it < a.niter; ++it) {
+        const int d = a.dil[it];
+        const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1[it]) +
+                           (size_t)(wm * MTW) * W_MT_STRIDE + lane;
+        const frag_t* w2 = reinterpret_cast<const frag_t*>(a.w2[it]) +
+                           (size_t)(wm * MTW) * W_MT_STRIDE + lane;
+        const float* b1 = a.b1[it];
+        const float* b2 = a.b2[it];
+
+        // ---- conv1 (dilation d) out of `a` ----
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        mma_taps<ET, K, KC, MTW, NTW, G, S>(
+            acc, abuf + (MA - H2 * d) * S + col_off, d * S, w1, W_MT_STRIDE,
+            afirst, w2);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int col = (wn * NTW + nt) * 32 + ln;
+                const int t = c_first + col;
+                const bool inside = t >= 0 && t < L;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = m_first + mt * 32 + 8 * g4 + 4 * lh;
+                    const float4 bias =
+                        *reinterpret_cast<const float4*>(b1 + co);
+                    float4 v;
+                    v.x = pm_lrelu(acc[mt][nt][4 * g4 + 0] + bias.x);
+                    v.y = pm_lrelu(acc[mt][nt][4 * g4 + 1] + bias.y);
+                    v.z = pm_lrelu(acc[mt][nt][4 * g4 + 2] + bias.z);
+                    v.w = pm_lrelu(acc[mt][nt][4 * g4 + 3] + bias.w);
+                    if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ET::store4(tbuf + (H2 + col) * S + co * ET::ESZ, v);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][nt][4 * g4 + r] = 0.f;
+                }
+            }
+        __syncthreads();
+
+        // ---- conv2 (dilation 1) out of `t`, residual into the trunk ----
+        const bool last = it + 1 == a.niter;
+        mma_taps<ET, K, KC, MTW, NTW, G, S>(
+            acc, tbuf + col_off, S, w2, W_MT_STRIDE, afirst,
+            last ? nullptr
+                 : reinterpret_cast<const frag_t*>(a.w1[it + 1]) +
+                       (size_t)(wm * MTW) * W_MT_STRIDE + lane);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int col = (wn * NTW + nt) * 32 + ln;
+                const int t = c_first + col;
+                const bool inside = t >= 0 && t < L;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = m_first + mt * 32 + 8 * g4 + 4 * lh;
+                    const float4 bias =
+                        *reinterpret_cast<const float4*>(b2 + co);
+                    float4 v;
+                    v.x = trunk[mt][nt][4 * g4 + 0] + acc[mt][nt][4 * g4 + 0] + bias.x;
+                    v.y = trunk[mt][nt][4 * g4 + 1] + acc[mt][nt][4 * g4 + 1] + bias.y;
+                    v.z = trunk[mt][nt][4 * g4 + 2] + acc[mt][nt][4 * g4 + 2] + bias.z;
+                    v.w = trunk[mt][nt][4 * g4 + 3] + acc[mt][nt][4 * g4 + 3] + bias.w;
+                    trunk[mt][nt][4 * g4 + 0] = v.x;
+                    trunk[mt][nt][4 * g4 + 1] = v.y;
+                    trunk[mt][nt][4 * g4 + 2] = v.z;
+                    trunk[mt][nt][4 * g4 + 3] = v.w;
+                    if (!last) {
+                        v.x = pm_lrelu(v.x); v.y = pm_lrelu(v.y);
+                        v.z = pm_lrelu(v.z); v.w = pm_lrelu(v.w);
+                        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        ET::store4(abuf + (MA + col) * S + co * ET::ESZ, v);
+                    }
+                }
+            }
+        if (!last) __syncthreads();
+    }
+
+    // ---- store the valid interior (+ MRF accumulate) ----------------------
+    float* ob = a.out + (size_t)b * L * C;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int col = (wn * NTW + nt) * 32 + ln;
+            const int t = c_first + col;
+            if (col >= a.halo && col < a.halo + a.TL && t < L) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = m_first + mt * 32 + 8 * g4 + 4 * lh;
+                    float4 v;
+                    v.x = trunk[mt][nt][4 * g4 + 0];
+                    v.y = trunk[mt][nt][4 * g4 + 1];
+                    v.z = trunk[mt][nt][4 * g4 + 2];
+                    v.w = trunk[mt][nt][4 * g4 + 3];
+                    float4* dst =
+                        reinterpret_cast<float4*>(ob + (size_t)t * C + co);
+                    if (a.mode == 1) {
+                        v.x *= a.scale; v.y *= a.scale;
+                        v.z *= a.scale; v.w *= a.scale;
+                    } else if (a.mode == 2) {
+                        const float4 o = *dst;
+                        v.x = o.x + v.x * a.scale; v.y = o.y + v.y * a.scale;
+                        v.z = o.z + v.z * a.scale; v.w = o.w + v.w * a.scale;
+                    }
+                    *dst = v;
+                }
+            }
+        }
 }

@@ -8,6 +8,11 @@ template <class ET> hipError_t pm_launch_pair(
     int C, int K, const PairArgs& args, hipStream_t stream);
 template <class ET> int pm_pair_tile_len(int C, int K);
 
+// Whole-Block fusion for C <= 64; returns hipErrorNotSupported when the shape
+// has no instantiation (caller falls back to the pair kernel).
+template <class ET> hipError_t pm_launch_block3(
+    int C, int K, const Block3Args& args, hipStream_t stream);
+
 // kind 0: plain conv with KT = KSPAN = 7 (input conv); kind 1: polyphase
 // ConvTranspose (KT = 2, KSPAN = 3). cfg: 0 = 256 x 128 tile, 1 = 64 x 128,
 // 2 = 32 x 128.
@@ -19,9 +24,13 @@ hipError_t pm_launch_stft(int epi, const SingleArgs& args, hipStream_t stream);
 
 // ---- fused pair geometry per (operand type, C) ---------------------------
 template <class ET, int C> struct PairCfg;
-// 16-bit operands: 128-column tiles everywhere
-template <> struct PairCfg<ElemF16, 256> { enum { WM = 4, WN = 2, NTW = 2 }; };
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2 }; };
+// 16-bit operands: every wave owns a 32 (co) x 128 (time) register tile, so
+// one A fragment (weights, streamed L2 -> VGPR) feeds 4 MFMAs: the vector
+// memory path, not the matrix pipe, was the limiter at 2 loads per 4 MFMAs
+// (rocprof r01: MFMA busy 43 %). C = 128 takes 256-column tiles
+// (LDS 160,480 B at k 11, d 5).
+template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4 }; };
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4 }; };
 template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2 }; };
 template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1 }; };
 template <int C> struct PairCfg<ElemBF16, C> : PairCfg<ElemF16, C> {};
@@ -83,6 +92,62 @@ int pm_pair_tile_len(int C, int K) {
         case 32: return PairCfg<ET, 32>::WN * PairCfg<ET, 32>::NTW * 32 - (K - 1);
     }
     return 0;
+}
+
+// ---- whole-Block fusion ---------------------------------------------------
+template <class ET, int C> struct Block3Cfg;
+template <> struct Block3Cfg<ElemF16, 32> { enum { WM = 1, WN = 8, NTW = 3 }; };
+template <> struct Block3Cfg<ElemF16, 64> { enum { WM = 2, WN = 4, NTW = 4 }; };
+template <int C> struct Block3Cfg<ElemBF16, C> : Block3Cfg<ElemF16, C> {};
+template <> struct Block3Cfg<ElemF32, 32> { enum { WM = 1, WN = 8, NTW = 2 }; };
+template <> struct Block3Cfg<ElemF32, 64> { enum { WM = 2, WN = 4, NTW = 2 }; };
+
+template <class ET, int C, int K>
+static hipError_t launch_block3_ck(const Block3Args& a0, hipStream_t stream) {
+    typedef Block3Cfg<ET, C> G;
+    constexpr int WM = G::WM, WN = G::WN, NTW = G::NTW;
+    constexpr int NC = WN * NTW * 32;
+    Block3Args a = a0;
+    a.halo = 0;
+    for (int i = 0; i < a.niter; ++i) a.halo += (a.dil[i] + 1) * ((K - 1) / 2);
+    a.TL = NC - 2 * a.halo;
+    if (a.TL < 32) return hipErrorNotSupported;
+    a.ntiles = (a.L + a.TL - 1) / a.TL;
+    auto kern = conv_block3_kernel<ET, C, K, WM, WN, NTW>;
+    constexpr int smem = block3_smem_bytes<ET, C, K, WM, WN, NTW>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(kern),
+            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.ntiles * a.B), dim3(WM * WN * 64), smem,
+                       stream, a);
+    return hipGetLastError();
+}
+
+template <class ET, int C>
+static hipError_t launch_block3_c(int K, const Block3Args& a, hipStream_t s) {
+    switch (K) {
+        case 3: return launch_block3_ck<ET, C, 3>(a, s);
+        case 7: return launch_block3_ck<ET, C, 7>(a, s);
+        case 11: return launch_block3_ck<ET, C, 11>(a, s);
+    }
+    return hipErrorNotSupported;
+}
+
+template <class ET>
+hipError_t pm_launch_block3(int C, int K, const Block3Args& a, hipStream_t s) {
+    for (int i = 0; i < a.niter; ++i)
+        if (a.dil[i] < 1 || a.dil[i] > 5) return hipErrorNotSupported;
+    if (a.niter < 1 || a.niter > 3) return hipErrorNotSupported;
+    switch (C) {
+        case 64: return launch_block3_c<ET, 64>(K, a, s);
+        case 32: return launch_block3_c<ET, 32>(K, a, s);
+    }
+    return hipErrorNotSupported;
 }
 
 // ---- single conv ----------------------------------------------------------

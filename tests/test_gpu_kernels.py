@@ -111,6 +111,60 @@ def test_block_iteration_short_and_modes(device):
     assert rel_err(got, prev + want / 3) < TOL['fp32']
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
+@pytest.mark.parametrize('channels', [32, 64, 16])
+@pytest.mark.parametrize('kernel_size', [3, 7, 11])
+def test_whole_block(device, dtype, channels, kernel_size):
+    """All three dilations of a Block fused in one kernel (trunk in
+    registers, halo recomputed) vs the oracle's unfused op sequence; lengths
+    around the tile size, shorter than the halo, and the MRF epilogues."""
+    import ctypes
+    _lib = lib()
+    gen = torch.Generator().manual_seed(channels + kernel_size)
+    std = 1. / (channels * kernel_size) ** .5
+    weights = {
+        name: [torch.randn(channels, channels, kernel_size, generator=gen) * std
+               for _ in range(3)] for name in ('w1', 'w2')}
+    biases = {
+        name: [torch.randn(channels, generator=gen) * .1 for _ in range(3)]
+        for name in ('b1', 'b2')}
+    dilations = (1, 3, 5)
+    state = {}
+    for n in range(3):
+        for which, (w, b) in enumerate((('w1', 'b1'), ('w2', 'b2')), 1):
+            state[f'p.convs{which}.{n}.weight'] = weights[w][n]
+            state[f'p.convs{which}.{n}.bias'] = biases[b][n]
+    on_device = {
+        name: [t.to(device).contiguous() for t in tensors]
+        for name, tensors in {**weights, **biases}.items()}
+
+    def pointers(name):
+        return (ctypes.c_void_p * 3)(*[t.data_ptr() for t in on_device[name]])
+
+    dil = (ctypes.c_int * 3)(*dilations)
+    ws = torch.empty(
+        3 * _lib.lib().pm_op_workspace_bytes(channels, channels, kernel_size),
+        dtype=torch.uint8, device=device)
+    for length, mode in ((700, 0), (1, 0), (50, 1), (649, 2), (1300, 2)):
+        x = torch.randn(2, channels, length, generator=gen)
+        prev = torch.randn(2, channels, length, generator=gen)
+        want = oracle.block(x, state, 'p', kernel_size, dilations)
+        if mode == 1:
+            want = want / 3
+        elif mode == 2:
+            want = prev + want / 3
+        x_cl = to_cl(x).to(device)
+        out = to_cl(prev).to(device)
+        _lib.check(_lib.lib().pm_block_cl(
+            _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out), pointers('w1'),
+            pointers('b1'), pointers('w2'), pointers('b2'), dil, 3, 2, length,
+            channels, kernel_size, mode, 1 / 3, ws.data_ptr(), ws.numel(),
+            _lib.stream()))
+        torch.cuda.synchronize()
+        tolerance = TOL[dtype] * (3 if dtype != 'fp32' else 1)
+        assert rel_err(from_cl(out, channels), want) < tolerance, (length, mode)
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'f16'])
 @pytest.mark.parametrize(
     'c_in,c_out,rate',
