@@ -169,7 +169,7 @@ __device__ __forceinline__ void mma_taps(
 #define PM_STAMP(args, i)                                                    \
     do {                                                                     \
         if ((args).timeline && threadIdx.x == 0)                             \
-            (args).timeline[(size_t)blockIdx.x * 8 + (i)] =                  \
+            (args).timeline[(size_t)blockIdx.x * 16 + (i)] =                  \
                 __builtin_amdgcn_s_memtime();                                \
     } while (0)
 
@@ -189,7 +189,7 @@ struct PairArgs {
     int mode;            // 0: out = y; 1: out = y * scale; 2: out += y * scale
     float scale;
     int ntiles;          // tiles per utterance
-    unsigned long long* timeline;   // debug: 8 s_memtime stamps per block
+    unsigned long long* timeline;   // debug: 16 s_memtime stamps per block
 };
 
 template <int C, int K, int WN, int NTW>
@@ -283,10 +283,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
             acc, cur + lane_off_x, d * SX, w1 + (size_t)c * W_CHUNK,
             W_MT_STRIDE, afirst,
             c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
+        if (c < 2) PM_STAMP(a, 6 + 3 * c);
         if (c + 1 < NCH) {
             char* nxt = xbuf + ((c + 1) & 1) * XR * SX;
             stager.template store<true>(nxt, XR, tid);
+            if (c < 2) PM_STAMP(a, 7 + 3 * c);
             __syncthreads();
+            if (c < 2) PM_STAMP(a, 8 + 3 * c);
         }
     }
 
@@ -579,7 +582,7 @@ struct Block3Args {
     int mode;            // 0: out = y; 1: out = y * scale; 2: out += y * scale
     float scale;
     int ntiles, halo, TL;
-    unsigned long long* timeline;   // debug: 8 s_memtime stamps per block
+    unsigned long long* timeline;   // debug: 16 s_memtime stamps per block
 };
 
 template <class ET, int C, int K, int WM, int WN, int NTW>

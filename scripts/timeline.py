@@ -22,7 +22,7 @@ for channels, length, k, d in ((256, 6888, 11, 5), (128, 55104, 11, 5),
     b2 = torch.zeros(channels, device=device)
     ws = torch.empty(lib.pm_op_workspace_bytes(channels, channels, k),
                      dtype=torch.uint8, device=device)
-    stamps = torch.zeros(1 << 18, 8, dtype=torch.int64, device=device)
+    stamps = torch.zeros(1 << 17, 16, dtype=torch.int64, device=device)
 
     def run():
         _lib.check(lib.pm_block_iteration_cl(
@@ -50,5 +50,8 @@ for channels, length, k, d in ((256, 6888, 11, 5), (128, 55104, 11, 5),
           f'(incl. packing), span {span:.0f} ticks, mean block {total:.0f} ticks')
     print('   stage %.0f | conv1 %.0f | epi1 %.0f | conv2 %.0f | epi2 %.0f' %
           tuple(phases.tolist()))
+    if channels > 64:
+        e = t[:, [6, 7, 8, 9, 10, 11]] - t[:, [1, 6, 7, 8, 9, 10]]
+        print('   chunk0: mma %.0f store %.0f sync %.0f | chunk1: mma %.0f store %.0f sync %.0f' % tuple(e.mean(0).tolist()))
     print('   blocks/CU %.2f -> sum of block time per CU %.0f ticks' %
           (n / 256, n / 256 * total))
