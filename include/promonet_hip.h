@@ -125,7 +125,8 @@ const char* pm_hifigan_profile_report(pm_hifigan_t h);
  *   pitch (B, T) Hz, periodicity (B, T), ppg (B, P, T)
  *   pitch_edges (NB) = Generator.pitch_distribution, pitch_table (NB, E)
  *   out_ref (B, P+E+bands+1, T) and/or out_cl (B, T, C_pad); either may be
- *   NULL.                                                                 */
+ *   NULL. period_rate > 0 appends the channel period_rate / clip(hz), the
+ *   pitch period in samples FARGAN reads (generator.py:191-195).          */
 int pm_prepare_features(const float* loudness, const float* pitch,
                         const float* periodicity, const float* ppg,
                         const float* pitch_edges, const float* pitch_table,
@@ -133,7 +134,8 @@ int pm_prepare_features(const float* loudness, const float* pitch,
                         int loudness_rows, int ppg_channels, int pitch_bins,
                         int embedding_size, int bands, int cl_channels,
                         float ppg_threshold, float fmin, float fmax,
-                        float min_db, float ref_db, void* stream);
+                        float min_db, float ref_db, float period_rate,
+                        void* stream);
 
 /* BaseGenerator.prepare_global_features (generator.py:49-70): speaker
  * embedding lookup + the two augmentation ratios -> (B, S + 2).           */
@@ -185,6 +187,31 @@ int pm_fold_weight_norm(const float* g, const float* v, float* w, int rows,
 /* (B, C, T) -> (B, T, c_pad) zero padded, and back                        */
 int pm_to_channels_last(const float* src, float* dst, int batch, int channels,
                         int frames, int c_pad, void* stream);
+
+/* ---- FARGAN vocoder engine: replaces promonet.model.FARGAN ---------------
+ * (promonet/model/fargan.py, selected by config/fargan.py MODEL = 'fargan').
+ * One persistent workgroup per utterance; weight_dtype PM_F32 or PM_F16 is
+ * the STORAGE type of the streamed weights (math is fp32).                 */
+typedef struct pm_fargan_s* pm_fargan_t;
+int pm_fargan_create(int num_features, int global_channels, int weight_dtype,
+                     pm_fargan_t* out);
+int pm_fargan_destroy(pm_fargan_t h);
+/* FARGAN.state_dict() keys, e.g. conditioning_network.0.weight (371,371),
+ * subframe_network.gru1.weight_ih (768,384),
+ * subframe_network.skip_glu.gate.weight_g (256,1) / weight_v (256,256)     */
+int pm_fargan_load_tensor(pm_fargan_t h, const char* name, const float* dev,
+                          const int64_t* shape, int ndim, void* stream);
+int pm_fargan_finalize(pm_fargan_t h, void* stream);
+size_t pm_fargan_workspace_bytes(pm_fargan_t h, int batch, int frames);
+/* FARGAN.forward(features, global_features, previous_samples)
+ * (fargan.py:21-59): features (B, 114, T) - last channel = pitch period in
+ * samples - or channels-last (B, T, 128) when features_cl != 0; global
+ * (Bg, 258); previous (Bp, 512) or NULL (zeros); out (B, 1, 256 T).         */
+int pm_fargan_forward(pm_fargan_t h, const float* features, int features_cl,
+                      const float* global_features, int global_batch,
+                      const float* previous_samples, int previous_batch,
+                      float* out, int batch, int frames, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ---- preprocessing: promonet/preprocess/spectrogram.py, loudness.py ---- */
 /* spectrogram.from_audio (spectrogram.py:15-60): reflect-pad 384, hann-1024

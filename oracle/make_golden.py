@@ -32,10 +32,50 @@ def run(which):
     import reference_import
     import restatement as oracle
 
-    configs = [small_config_file()] if which == 'small' else []
+    configs = {
+        'small': [small_config_file()],
+        'fargan': [reference_import.REFERENCE_ROOT / 'config' / 'fargan.py'],
+    }.get(which, [])
     promonet = reference_import.load(configs)
     torch.manual_seed(0)
     GOLDEN.mkdir(parents=True, exist_ok=True)
+
+    if which == 'fargan':
+        # config/fargan.py: frame-autoregressive GRU vocoder
+        assert promonet.MODEL == 'fargan'
+        assert promonet.NUM_PREVIOUS_SAMPLES == 512
+        model = promonet.model.Generator().eval()
+        reference_state = model.state_dict()
+        state = oracle.random_state_fargan(seed=0)
+        state['pitch_distribution'] = \
+            reference_state['pitch_distribution'].clone()
+        model.load_state_dict(state)
+        golden = {
+            'seed': 0,
+            'state_keys': {
+                k: tuple(v.shape) for k, v in reference_state.items()},
+            'num_previous_samples': promonet.NUM_PREVIOUS_SAMPLES}
+        gen = torch.Generator().manual_seed(2)
+        for name, (batch, frames, seed) in {
+            'b2_t8': (2, 8, 3), 'b1_t60': (1, 60, 4), 'b3_t25': (3, 25, 6)
+        }.items():
+            inputs = oracle.synthetic_inputs(batch, frames, seed=seed)
+            previous = torch.rand(batch, 1, 512, generator=gen) * .2 - .1 \
+                if name == 'b3_t25' else torch.zeros(batch, 1, 512)
+            with torch.inference_mode():
+                audio = model(*inputs, previous)
+                features = model.prepare_features(*inputs[:4])
+                mine = oracle.fargan_generator_forward(
+                    *inputs, state, previous)
+            error = (audio - mine).abs().max().item()
+            print(f'fargan {name}: restatement vs reference {error:.3e}')
+            assert error < 1e-6 and features.shape[1] == 114
+            golden[name] = {
+                'batch': batch, 'frames': frames, 'input_seed': seed,
+                'previous': previous, 'audio': audio,
+                'period': features[:, -1].clone()}
+        torch.save(golden, GOLDEN / 'generator_fargan.pt')
+        return
 
     if which == 'small':
         assert promonet.HIFIGAN_UPSAMPLE_INITIAL_SIZE == 64
@@ -148,7 +188,7 @@ if __name__ == '__main__':
     if len(sys.argv) > 1:
         run(sys.argv[1])
     else:
-        for which in ('small', 'default'):
+        for which in ('small', 'default', 'fargan'):
             subprocess.run(
                 [sys.executable, __file__, which], check=True)
         for file in sorted(GOLDEN.iterdir()):

@@ -508,3 +508,196 @@ def loudness(audio, bands=1):
     weighted[weighted < MIN_DB] = MIN_DB
     out = torch.from_numpy(weighted).float()
     return band_average(out, bands) if bands is not None else out
+
+
+###############################################################################
+# FARGAN (config/fargan.py): frame-autoregressive GRU vocoder
+###############################################################################
+
+FARGAN_SUBFRAMES = 4                            # defaults.py:244
+FARGAN_SUBFRAME_SIZE = HOPSIZE // 4             # defaults.py:247
+FARGAN_PREVIOUS_SAMPLES = HOPSIZE * 2           # static.py:71-72
+
+
+def fold_weight_norm_linear(g, v):
+    """weight_norm on a Linear (dim=0): per output row, g (O, 1), v (O, I)."""
+    return v * (g / torch.linalg.vector_norm(v, dim=1, keepdim=True))
+
+
+def fargan_weights(state):
+    """Folded FARGAN weights from a reference-keyed Generator state dict."""
+    p = 'model.subframe_network.'
+    w = {}
+    for i, key in enumerate((0, 2, 4)):
+        w[f'cond{i}'] = state[f'model.conditioning_network.{key}.weight']
+
+    def normed(prefix):
+        if prefix + '.weight' in state:
+            return state[prefix + '.weight']
+        return fold_weight_norm_linear(
+            state[prefix + '.weight_g'], state[prefix + '.weight_v'])
+
+    w['fwconv'] = normed(p + 'framewise_convolution.model.0')
+    w['fwconv_glu'] = normed(p + 'framewise_convolution.model.2.gate')
+    for n in (1, 2, 3):
+        w[f'gru{n}_ih'] = state[p + f'gru{n}.weight_ih']
+        w[f'gru{n}_hh'] = state[p + f'gru{n}.weight_hh']
+        w[f'gru{n}_glu'] = normed(p + f'gru{n}_glu.gate')
+    w['skip_glu'] = normed(p + 'skip_glu.gate')
+    w['skip'] = state[p + 'skip_dense.weight']
+    w['out'] = state[p + 'output_layer.weight']
+    return w
+
+
+def _glu(x, gate):
+    """model/fargan.py:375-388"""
+    return x * torch.sigmoid(F.linear(x, gate))
+
+
+def _gru_cell(x, h, w_ih, w_hh):
+    """torch.nn.GRUCell(bias=False) (model/fargan.py:212-223)."""
+    gi, gh = F.linear(x, w_ih), F.linear(h, w_hh)
+    i_r, i_z, i_n = gi.chunk(3, 1)
+    h_r, h_z, h_n = gh.chunk(3, 1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return (1 - z) * n + z * h
+
+
+def fargan_subframe(w, features, previous_samples, period, states):
+    """SubframeNetwork.forward in eval mode, FARGAN_GAIN_NORMALIZATION off
+    (model/fargan.py:199-335). previous_samples (B, 512)."""
+    size = FARGAN_SUBFRAME_SIZE
+    total = previous_samples.shape[-1]
+    index = total - period[:, None] + torch.arange(size + 4)[None] - 2
+    index = index - period[:, None] * (index >= total)          # :233-237
+    lookback = torch.gather(previous_samples, 1, index)         # :238-241
+    previous_subframe = previous_samples[:, -size:]             # :244-246
+    subframe_input = torch.cat(
+        (features, previous_subframe, lookback), dim=1)         # :254-256
+    fwconv = _glu(
+        torch.tanh(F.linear(
+            torch.cat((subframe_input, states[3]), -1), w['fwconv'])),
+        w['fwconv_glu'])                                        # :257-259, :366
+    lookback = lookback[:, 2:-2]                                # :260
+    outs, new_states = [], []
+    x = fwconv
+    for n in (1, 2, 3):                                         # :269-314
+        h = _gru_cell(
+            torch.cat((x, lookback, previous_subframe), dim=1),
+            states[n - 1], w[f'gru{n}_ih'], w[f'gru{n}_hh'])
+        x = _glu(h, w[f'gru{n}_glu'])
+        outs.append(x)
+        new_states.append(h)
+    skip = torch.cat(
+        outs + [fwconv, lookback, previous_subframe], dim=1)    # :317-326
+    skip = _glu(torch.tanh(F.linear(skip, w['skip'])), w['skip_glu'])
+    output = torch.tanh(F.linear(skip, w['out']))               # :333
+    return output, (*new_states, subframe_input)
+
+
+def fargan_forward(features, global_features, previous_samples, state,
+                   return_states=False):
+    """FARGAN.forward (model/fargan.py:21-59) + step (:65-131).
+
+    features (B, 114, T) with the pitch period (in samples) as the last
+    channel, global_features (B, 258, 1), previous_samples (B, 1, 512) ->
+    (B, 1, 256 T)."""
+    w = fargan_weights(state)
+    batch = features.shape[0]
+    prev = previous_samples[:, 0].expand(batch, -1).clone()
+    glob = global_features.squeeze(2).expand(batch, -1)
+    states = (
+        torch.zeros(batch, HOPSIZE), torch.zeros(batch, HOPSIZE),
+        torch.zeros(batch, HOPSIZE),
+        torch.zeros(batch, 4 * FARGAN_SUBFRAME_SIZE + 4))       # :406-415
+    frames = []
+    for frame in features.permute(2, 0, 1):
+        period = torch.round(frame[:, -1]).to(torch.long)       # :94
+        x = torch.cat((frame[:, :-1], glob), dim=1)
+        for i in range(3):                                      # :139-160
+            x = torch.tanh(F.linear(x, w[f'cond{i}']))
+        # reshape(B, 128, 4).permute(2, 0, 1): sub-frame s takes x[:, s::4]
+        subframes = x.reshape(batch, 2 * FARGAN_SUBFRAME_SIZE,
+                              FARGAN_SUBFRAMES).permute(2, 0, 1)
+        for sub in subframes:
+            out, states = fargan_subframe(w, sub, prev, period, states)
+            frames.append(out)
+            prev = torch.cat((prev[:, FARGAN_SUBFRAME_SIZE:], out), dim=1)
+    signal = torch.cat(frames, dim=1).unsqueeze(1)
+    if return_states:
+        return signal, states, prev
+    return signal
+
+
+def fargan_generator_forward(
+    loudness, pitch, periodicity, ppg, speakers, spectral_balance_ratios,
+    loudness_ratios, state, previous_samples=None
+):
+    """Generator.forward with MODEL == 'fargan' (model/generator.py:116-135,
+    period channel :191-195)."""
+    features = prepare_features(
+        loudness, pitch, periodicity, ppg, state['pitch_distribution'],
+        state['pitch_embedding.weight'], state['ppg_threshold'])
+    period = SAMPLE_RATE / torch.clip(pitch, FMIN, FMAX)
+    features = torch.cat((features, period[:, None]), dim=1)
+    global_features = prepare_global_features(
+        speakers, spectral_balance_ratios, loudness_ratios,
+        state['speaker_embedding.weight'])
+    if previous_samples is None:
+        previous_samples = torch.zeros(
+            features.shape[0], 1, FARGAN_PREVIOUS_SAMPLES)
+    return fargan_forward(features, global_features, previous_samples, state)
+
+
+def random_state_fargan(seed=0, pitch_distribution=None):
+    """Reference-keyed FARGAN Generator state dict with the reference's init
+    scheme (orthogonal Linear weights, model/fargan.py:418-424; GRUCell
+    default U(-1/sqrt(H), 1/sqrt(H)); weight-normed layers g = ||v||)."""
+    gen = torch.Generator().manual_seed(seed)
+
+    def orthogonal(rows, cols):
+        return torch.nn.init.orthogonal_(torch.empty(rows, cols), generator=gen)
+
+    state = {
+        'default_previous_samples': torch.zeros(1, 1, FARGAN_PREVIOUS_SAMPLES),
+        'ppg_threshold': torch.tensor(SPARSE_PPG_THRESHOLD)}
+    if pitch_distribution is None:
+        pitch_distribution = torch.exp(torch.linspace(
+            math.log(55.9431), math.log(547.3264), PITCH_BINS))
+    state['pitch_distribution'] = pitch_distribution.clone().float()
+    channels = NUM_FEATURES + GLOBAL_CHANNELS
+    state['model.conditioning_network.0.weight'] = orthogonal(channels, channels)
+    state['model.conditioning_network.2.weight'] = orthogonal(channels, channels)
+    state['model.conditioning_network.4.weight'] = orthogonal(
+        2 * HOPSIZE, channels)
+    p = 'model.subframe_network.'
+
+    def normed(prefix, rows, cols):
+        v = orthogonal(rows, cols)
+        state[prefix + '.weight_g'] = torch.linalg.vector_norm(
+            v, dim=1, keepdim=True)
+        state[prefix + '.weight_v'] = v
+
+    normed(p + 'framewise_convolution.model.0', HOPSIZE,
+           2 * (4 * FARGAN_SUBFRAME_SIZE + 4))
+    normed(p + 'framewise_convolution.model.2.gate', HOPSIZE, HOPSIZE)
+    bound = 1. / math.sqrt(HOPSIZE)
+    for n in (1, 2, 3):
+        state[p + f'gru{n}.weight_ih'] = (torch.rand(
+            3 * HOPSIZE, HOPSIZE + 2 * FARGAN_SUBFRAME_SIZE,
+            generator=gen) * 2 - 1) * bound
+        state[p + f'gru{n}.weight_hh'] = (torch.rand(
+            3 * HOPSIZE, HOPSIZE, generator=gen) * 2 - 1) * bound
+    for name in ('gru1_glu', 'gru2_glu', 'gru3_glu', 'skip_glu'):
+        normed(p + name + '.gate', HOPSIZE, HOPSIZE)
+    state[p + 'skip_dense.weight'] = orthogonal(
+        HOPSIZE, 4 * HOPSIZE + 2 * FARGAN_SUBFRAME_SIZE)
+    state[p + 'output_layer.weight'] = orthogonal(
+        FARGAN_SUBFRAME_SIZE, HOPSIZE)
+    state['speaker_embedding.weight'] = torch.randn(
+        NUM_SPEAKERS, SPEAKER_CHANNELS, generator=gen)
+    state['pitch_embedding.weight'] = torch.randn(
+        PITCH_BINS, PITCH_EMBEDDING_SIZE, generator=gen)
+    return state

@@ -54,7 +54,7 @@ SIGNATURES = {
     'pm_hifigan_profile_collect': (_I, [_P]),
     'pm_hifigan_profile_reset': (_I, [_P]),
     'pm_hifigan_profile_report': (ctypes.c_char_p, [_P]),
-    'pm_prepare_features': (_I, [_P] * 8 + [_I] * 8 + [_F] * 5 + [_P]),
+    'pm_prepare_features': (_I, [_P] * 8 + [_I] * 8 + [_F] * 6 + [_P]),
     'pm_prepare_global_features': (_I, [_P] * 5 + [_I, _I, _P]),
     'pm_op_workspace_bytes': (_S, [_I, _I, _I]),
     'pm_block_iteration_cl': (_I, [_I] + [_P] * 6 + [_I] * 6 + [_F, _P, _S, _P]),
@@ -64,6 +64,12 @@ SIGNATURES = {
     'pm_debug_timeline': (_I, [_P]),
     'pm_fold_weight_norm': (_I, [_P, _P, _P, _I, _I, _P]),
     'pm_to_channels_last': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'pm_fargan_create': (_I, [_I, _I, _I, ctypes.POINTER(_P)]),
+    'pm_fargan_destroy': (_I, [_P]),
+    'pm_fargan_load_tensor': (_I, [_P, ctypes.c_char_p, _P, c_int64_p, _I, _P]),
+    'pm_fargan_finalize': (_I, [_P, _P]),
+    'pm_fargan_workspace_bytes': (_S, [_P, _I, _I]),
+    'pm_fargan_forward': (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _S, _P]),
     'pm_stft_scratch_bytes': (_S, [_I, _I]),
     'pm_stft_magnitude': (_I, [_P, _P, _I, _I, _P, _S, _P]),
     'pm_linear_to_mel': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

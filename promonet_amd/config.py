@@ -51,6 +51,11 @@ ZERO_SHOT = False
 STEPS = 800000
 NUM_WORKERS = 10
 
+# Storage type of the streamed FARGAN weights ('fp32' or 'f16'; math is fp32)
+FARGAN_WEIGHT_DTYPE = 'fp32'
+FARGAN_PREVIOUS_FRAMES = 2
+FARGAN_SUBFRAMES = 4
+
 # MFMA operand type of the HIP engine: 'f16' (default; passes the 1e-4
 # parity gate at the bf16 MFMA rate), 'bf16', or 'fp32' (exact)
 COMPUTE_DTYPE = 'f16'
@@ -76,7 +81,8 @@ def derived():
             PITCH_EMBEDDING_SIZE if PITCH_EMBEDDING else 1))    # static.py:48-53
     g['NUM_SPEAKERS'] = {
         'daps': 20, 'libritts': 1230, 'vctk': 109}[TRAINING_DATASET]
-    g['NUM_PREVIOUS_SAMPLES'] = 1                               # static.py:69-74
+    g['NUM_PREVIOUS_SAMPLES'] = (
+        HOPSIZE * FARGAN_PREVIOUS_FRAMES if MODEL == 'fargan' else 1)  # static.py:69-74
 
 
 derived()

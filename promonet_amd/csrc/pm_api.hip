@@ -17,6 +17,7 @@
 #include "pm_launch.h"
 #include "pm_misc.h"
 #include "pm_stft.h"
+#include "pm_fargan.h"
 
 #define PM_VERSION 100
 
@@ -741,13 +742,13 @@ extern "C" int pm_prepare_features(
     const float* ppg, const float* pitch_edges, const float* pitch_table,
     float* out_ref, float* out_cl, int B, int T, int F, int P, int NB, int E,
     int bands, int cl_channels, float ppg_threshold, float fmin, float fmax,
-    float min_db, float ref_db, void* stream) {
+    float min_db, float ref_db, float period_rate, void* stream) {
     if (!loudness || !pitch || !periodicity || !ppg || !pitch_edges ||
         !pitch_table || (!out_ref && !out_cl))
         return fail(PM_EINVAL, "null argument");
     if (B < 1 || T < 1 || P < 2 || bands < 1 || bands > 16 || F < bands)
         return fail(PM_EINVAL, "bad feature dimensions");
-    const int C = P + E + bands + 1;
+    const int C = P + E + bands + 1 + (period_rate > 0.f ? 1 : 0);
     if (out_cl && cl_channels < C)
         return fail(PM_EINVAL, "cl_channels %d < %d", cl_channels, C);
     FeatureArgs a;
@@ -765,6 +766,7 @@ extern "C" int pm_prepare_features(
     a.rank_weight = rank - floorf(rank);
     a.fmin = fmin; a.fmax = fmax; a.min_db = min_db;
     a.db_range = ref_db - min_db;
+    a.period_rate = period_rate;
     constexpr int TH = 128;
     hipLaunchKernelGGL(pm_prepare_features_kernel<TH>,
                        dim3((T + TH - 1) / TH, B), dim3(TH),
@@ -1066,4 +1068,212 @@ extern "C" int pm_loudness(
                        dim3(256), 0, s, a);
     HIP_TRY(hipGetLastError());
     return PM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// FARGAN engine (config/fargan.py): replaces promonet.model.FARGAN
+// ---------------------------------------------------------------------------
+struct FLayer {
+    const char* key;     // state-dict prefix (without .weight / .weight_g ...)
+    const char* leaf;    // leaf of a plain tensor ("weight", "weight_ih", ...)
+    bool normed;         // weight-normed Linear: accepts weight_g + weight_v
+    int rows, cols, rpad, kpad;
+    void* packed = nullptr;
+    float* tmp_g = nullptr;
+    float* tmp_v = nullptr;
+    bool has = false;
+};
+
+struct pm_fargan_s {
+    int nfeat, G, dtype;
+    std::vector<FLayer> layers;
+    bool finalized = false;
+};
+
+#define FG_P "subframe_network."
+static std::vector<FLayer> fargan_layers(int nin) {
+    const int cpad = 376;
+    std::vector<FLayer> l = {
+        {"conditioning_network.0", "weight", false, nin, nin, 384, cpad},
+        {"conditioning_network.2", "weight", false, nin, nin, 384, cpad},
+        {"conditioning_network.4", "weight", false, 512, nin, 512, cpad},
+        {FG_P "framewise_convolution.model.0", "weight", true, 256, 520, 256, 520},
+        {FG_P "framewise_convolution.model.2.gate", "weight", true, 256, 256, 256, 256},
+        {FG_P "gru1", "weight_ih", false, 768, 384, 768, 384},
+        {FG_P "gru2", "weight_ih", false, 768, 384, 768, 384},
+        {FG_P "gru3", "weight_ih", false, 768, 384, 768, 384},
+        {FG_P "gru1", "weight_hh", false, 768, 256, 768, 256},
+        {FG_P "gru2", "weight_hh", false, 768, 256, 768, 256},
+        {FG_P "gru3", "weight_hh", false, 768, 256, 768, 256},
+        {FG_P "gru1_glu.gate", "weight", true, 256, 256, 256, 256},
+        {FG_P "gru2_glu.gate", "weight", true, 256, 256, 256, 256},
+        {FG_P "gru3_glu.gate", "weight", true, 256, 256, 256, 256},
+        {FG_P "skip_dense", "weight", false, 256, 1152, 256, 1152},
+        {FG_P "skip_glu.gate", "weight", true, 256, 256, 256, 256},
+        {FG_P "output_layer", "weight", false, 64, 256, 64, 256},
+    };
+    return l;
+}
+
+extern "C" int pm_fargan_create(
+    int num_features, int global_channels, int weight_dtype,
+    pm_fargan_t* out) {
+    if (!out) return fail(PM_EINVAL, "null argument");
+    if (num_features + global_channels != 371 || num_features < 1)
+        return fail(PM_EINVAL,
+                    "FARGAN kernel is built for 113 + 258 conditioning "
+                    "channels (config/fargan.py)");
+    if (weight_dtype != PM_F32 && weight_dtype != PM_F16)
+        return fail(PM_EINVAL, "weight dtype must be PM_F32 or PM_F16");
+    auto* h = new pm_fargan_s();
+    h->nfeat = num_features; h->G = global_channels; h->dtype = weight_dtype;
+    h->layers = fargan_layers(num_features + global_channels);
+    *out = h;
+    return PM_OK;
+}
+
+extern "C" int pm_fargan_destroy(pm_fargan_t h) {
+    if (!h) return PM_OK;
+    for (auto& l : h->layers) {
+        if (l.packed) hipFree(l.packed);
+        if (l.tmp_g) hipFree(l.tmp_g);
+        if (l.tmp_v) hipFree(l.tmp_v);
+    }
+    delete h;
+    return PM_OK;
+}
+
+static int fargan_pack(pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) {
+    const size_t elems = (size_t)l.rpad * l.kpad;
+    if (!l.packed)
+        HIP_TRY(hipMalloc(&l.packed, elems * (h->dtype == PM_F32 ? 4 : 2)));
+    const unsigned grid = (unsigned)((elems + 255) / 256);
+    if (h->dtype == PM_F32)
+        hipLaunchKernelGGL(pm_fargan_pack_kernel<float>, dim3(grid), dim3(256),
+                           0, s, w, (float*)l.packed, l.rows, l.cols, l.rpad,
+                           l.kpad);
+    else
+        hipLaunchKernelGGL(pm_fargan_pack_kernel<_Float16>, dim3(grid),
+                           dim3(256), 0, s, w, (_Float16*)l.packed, l.rows,
+                           l.cols, l.rpad, l.kpad);
+    HIP_TRY(hipGetLastError());
+    l.has = true;
+    return PM_OK;
+}
+
+extern "C" int pm_fargan_load_tensor(
+    pm_fargan_t h, const char* name, const float* dev, const int64_t* shape,
+    int ndim, void* stream) {
+    if (!h || !name || !dev || !shape) return fail(PM_EINVAL, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    for (auto& l : h->layers) {
+        const size_t n = strlen(l.key);
+        if (strncmp(name, l.key, n) || name[n] != '.') continue;
+        const char* leaf = name + n + 1;
+        if (!strcmp(leaf, l.leaf)) {
+            if (ndim != 2 || shape[0] != l.rows || shape[1] != l.cols)
+                return fail(PM_EINVAL, "%s: expected shape (%d, %d)", name,
+                            l.rows, l.cols);
+            int rc = fargan_pack(h, l, dev, s);
+            if (rc) return rc;
+        } else if (l.normed && (!strcmp(leaf, "weight_g") ||
+                                !strcmp(leaf, "weight_v"))) {
+            const bool is_g = leaf[7] == 'g';
+            if (is_g) {
+                if (ndim != 2 || shape[0] != l.rows || shape[1] != 1)
+                    return fail(PM_EINVAL, "%s: expected (%d, 1)", name, l.rows);
+                int rc = copy_dev(&l.tmp_g, dev, l.rows, s);
+                if (rc) return rc;
+            } else {
+                if (ndim != 2 || shape[0] != l.rows || shape[1] != l.cols)
+                    return fail(PM_EINVAL, "%s: expected (%d, %d)", name,
+                                l.rows, l.cols);
+                int rc = copy_dev(&l.tmp_v, dev, (size_t)l.rows * l.cols, s);
+                if (rc) return rc;
+            }
+            if (l.tmp_g && l.tmp_v) {
+                float* folded = nullptr;
+                HIP_TRY(hipMalloc((void**)&folded,
+                                  (size_t)l.rows * l.cols * sizeof(float)));
+                hipLaunchKernelGGL(pm_fold_kernel, dim3(l.rows), dim3(256), 0,
+                                   s, l.tmp_g, l.tmp_v, folded, l.cols);
+                HIP_TRY(hipGetLastError());
+                int rc = fargan_pack(h, l, folded, s);
+                HIP_TRY(hipStreamSynchronize(s));
+                hipFree(folded); hipFree(l.tmp_g); hipFree(l.tmp_v);
+                l.tmp_g = l.tmp_v = nullptr;
+                if (rc) return rc;
+            }
+        } else {
+            continue;   // e.g. gru1.weight_hh is a different table row
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        h->finalized = false;
+        return PM_OK;
+    }
+    return fail(PM_EINVAL, "%s: not a FARGAN state-dict key", name);
+}
+
+extern "C" int pm_fargan_finalize(pm_fargan_t h, void* stream) {
+    if (!h) return fail(PM_EINVAL, "null handle");
+    for (auto& l : h->layers)
+        if (!l.has)
+            return fail(PM_ESTATE, "missing tensor: %s.%s", l.key, l.leaf);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    h->finalized = true;
+    return PM_OK;
+}
+
+extern "C" size_t pm_fargan_workspace_bytes(pm_fargan_t h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    return align256((size_t)B * T * pad32(h->nfeat + 1) * sizeof(float));
+}
+
+template <class WT>
+static int fargan_launch(
+    pm_fargan_t h, const FarganArgs& a, hipStream_t s) {
+    FarganWeights<WT> w;
+    auto P = [&](int i) { return (const WT*)h->layers[i].packed; };
+    w.cond[0] = P(0); w.cond[1] = P(1); w.cond[2] = P(2);
+    w.fwconv = P(3); w.fwconv_glu = P(4);
+    for (int n = 0; n < 3; ++n) {
+        w.gru_ih[n] = P(5 + n); w.gru_hh[n] = P(8 + n); w.gru_glu[n] = P(11 + n);
+    }
+    w.skip = P(14); w.skip_glu = P(15); w.out = P(16);
+    hipLaunchKernelGGL(pm_fargan_kernel<WT>, dim3(a.B), dim3(FG_THREADS), 0, s,
+                       a, w);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+// FARGAN.forward (model/fargan.py:21-59): features (B, nfeat + 1, T) with the
+// pitch period as last channel (or channels-last (B, T, pad32(nfeat + 1)) when
+// features_cl != 0), global (Bg, G), previous (Bp, 512) or NULL -> (B, 1, 256 T)
+extern "C" int pm_fargan_forward(
+    pm_fargan_t h, const float* features, int features_cl, const float* g,
+    int gbatch, const float* previous, int pbatch, float* out, int B, int T,
+    void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !features || !g || !out) return fail(PM_EINVAL, "null argument");
+    if (!h->finalized) return fail(PM_ESTATE, "pm_fargan_finalize not called");
+    if (B < 1 || T < 1) return fail(PM_EINVAL, "empty batch or sequence");
+    if ((gbatch != 1 && gbatch != B) || (previous && pbatch != 1 && pbatch != B))
+        return fail(PM_EINVAL, "broadcast batch must be 1 or batch");
+    hipStream_t s = (hipStream_t)stream;
+    const int cpad = pad32(h->nfeat + 1);
+    const float* fcl = features;
+    if (!features_cl) {
+        if (!ws || ws_bytes < pm_fargan_workspace_bytes(h, B, T))
+            return fail(PM_ENOMEM, "workspace too small");
+        dim3 grid((T + 31) / 32, cpad / 32, B);
+        hipLaunchKernelGGL(pm_to_channels_last_kernel, grid, dim3(256), 0, s,
+                           features, (float*)ws, h->nfeat + 1, T, cpad);
+        HIP_TRY(hipGetLastError());
+        fcl = (const float*)ws;
+    }
+    FarganArgs a;
+    a.features_cl = fcl; a.global = g; a.previous = previous; a.out = out;
+    a.B = B; a.T = T; a.cstride = cpad; a.nfeat = h->nfeat; a.G = h->G;
+    a.global_batch = gbatch; a.previous_batch = pbatch;
+    return h->dtype == PM_F32 ? fargan_launch<float>(h, a, s)
+                              : fargan_launch<_Float16>(h, a, s);
 }

@@ -1,0 +1,262 @@
+// FARGAN: frame-autoregressive GRU vocoder (reference: promonet/model/fargan.py,
+// config/fargan.py). 4 dependent sub-frame steps per frame, ~11 dependent
+// dense layers per step: latency-bound, not FLOP-bound (74 kFLOP / sample).
+//
+// Mapping (round 1): ONE PERSISTENT WORKGROUP PER UTTERANCE walks the whole
+// sequence; every recurrent quantity (3 GRU states, the 260-wide framewise
+// state, the last 512 output samples) stays in LDS for the entire utterance,
+// HBM sees one feature row in and 256 samples out per frame. Each dense layer
+// is a matrix-vector product with thread <-> output row, the weights streamed
+// from L2 (2.76 M parameters do not fit a CU) in a [k / VEC][row][VEC] packing
+// so a wave reads 1 KB of consecutive rows per instruction and needs no
+// cross-lane reduction; short layers split K over thread groups and reduce
+// through LDS. Utterances are independent -> B workgroups run concurrently.
+#pragma once
+#include "pm_common.h"
+
+#define FG_THREADS 768
+#define FG_HOP 256
+#define FG_SUB 64
+#define FG_PREV 512
+#define FG_SUBIN 260          // 128 features + 64 previous + 68 lookback
+#define FG_SKIP 1152
+
+template <class WT> struct FgVec;
+template <> struct FgVec<float> {
+    static constexpr int VEC = 4;
+    __device__ static __forceinline__ float dot(
+        const float* __restrict__ w, const float* x) {
+        const float4 a = *reinterpret_cast<const float4*>(w);
+        const float4 b = *reinterpret_cast<const float4*>(x);
+        return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+};
+template <> struct FgVec<_Float16> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float dot(
+        const _Float16* __restrict__ w, const float* x) {
+        const half8 a = *reinterpret_cast<const half8*>(w);
+        const float4 b0 = *reinterpret_cast<const float4*>(x);
+        const float4 b1 = *reinterpret_cast<const float4*>(x + 4);
+        return (float)a[0] * b0.x + (float)a[1] * b0.y + (float)a[2] * b0.z +
+               (float)a[3] * b0.w + (float)a[4] * b1.x + (float)a[5] * b1.y +
+               (float)a[6] * b1.z + (float)a[7] * b1.w;
+    }
+};
+
+// Partial matrix-vector product for thread `tid` of a (RPAD x PARTS) team:
+// row = tid % RPAD, K-slice = tid / RPAD. x is an LDS vector; columns
+// [0, split) come from xa, [split, K) from xb (split a multiple of VEC).
+template <class WT, int RPAD, int PARTS>
+__device__ __forceinline__ float fg_gemv(
+    const WT* __restrict__ w, const float* xa, const float* xb, int split,
+    int kpad, int tid) {
+    constexpr int VEC = FgVec<WT>::VEC;
+    const int row = tid % RPAD, part = tid / RPAD;
+    const int blocks = kpad / VEC;
+    const int b0 = part * blocks / PARTS, b1 = (part + 1) * blocks / PARTS;
+    const int sb = split / VEC;
+    const WT* wp = w + ((size_t)b0 * RPAD + row) * VEC;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) {
+        const float* x = b < sb ? xa + b * VEC : xb + (b - sb) * VEC;
+        acc += FgVec<WT>::dot(wp, x);
+        wp += (size_t)RPAD * VEC;
+    }
+    return acc;
+}
+
+// torch-layout W (rows, cols) fp32 -> [kpad / VEC][rpad][VEC], zero padded
+template <class WT>
+__global__ __launch_bounds__(256) void pm_fargan_pack_kernel(
+    const float* __restrict__ w, WT* __restrict__ out, int rows, int cols,
+    int rpad, int kpad) {
+    constexpr int VEC = FgVec<WT>::VEC;
+    const long long total = (long long)rpad * kpad;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int e = i % VEC;
+    const int row = (i / VEC) % rpad;
+    const int blk = i / ((long long)VEC * rpad);
+    const int col = blk * VEC + e;
+    out[i] = (WT)((row < rows && col < cols) ? w[(size_t)row * cols + col]
+                                             : 0.f);
+}
+
+template <class WT>
+struct FarganWeights {
+    const WT* cond[3];        // 384x372, 384x372, 512x372 (padded)
+    const WT* fwconv;         // 256 x 520
+    const WT* fwconv_glu;     // 256 x 256
+    const WT* gru_ih[3];      // 768 x 384
+    const WT* gru_hh[3];      // 768 x 256
+    const WT* gru_glu[3];     // 256 x 256
+    const WT* skip;           // 256 x 1152
+    const WT* skip_glu;       // 256 x 256
+    const WT* out;            // 64 x 256
+};
+
+struct FarganArgs {
+    const float* features_cl;   // (B, T, cstride): 113 features, then period
+    const float* global;        // (Bg, G)
+    const float* previous;      // (Bp, 512) or null (zeros)
+    float* out;                 // (B, 256 T)
+    int B, T, cstride, nfeat, G;
+    int global_batch, previous_batch;
+};
+
+__device__ __forceinline__ float fg_sigmoid(float v) {
+    return 1.f / (1.f + expf(-v));
+}
+
+template <class WT>
+__global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
+    FarganArgs a, FarganWeights<WT> w) {
+    constexpr int NT = FG_THREADS;
+    constexpr int CPAD = 376;   // 371 conditioning inputs, padded to x8
+    __shared__ __attribute__((aligned(16))) float condin[CPAD];
+    __shared__ __attribute__((aligned(16))) float c1[CPAD];
+    __shared__ __attribute__((aligned(16))) float c2[CPAD];
+    __shared__ __attribute__((aligned(16))) float cond[512];
+    __shared__ __attribute__((aligned(16))) float subin[2 * FG_SUBIN + 8];
+    __shared__ __attribute__((aligned(16))) float skipbuf[FG_SKIP];
+    __shared__ __attribute__((aligned(16))) float hid[3][FG_HOP];
+    __shared__ __attribute__((aligned(16))) float f1[FG_HOP];
+    __shared__ __attribute__((aligned(16))) float part[NT];
+    __shared__ __attribute__((aligned(16))) float part2[NT];
+    __shared__ float prev[FG_PREV];
+    __shared__ int s_period;
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int T = a.T;
+    const float* feat = a.features_cl + (size_t)b * T * a.cstride;
+    const float* glob =
+        a.global + (size_t)(a.global_batch == 1 ? 0 : b) * a.G;
+    float* out = a.out + (size_t)b * T * FG_HOP;
+    const int nin = a.nfeat + a.G;   // 371
+
+    // ---- initial recurrent state (fargan.py:406-415) ----
+    for (int i = tid; i < 3 * FG_HOP; i += NT) (&hid[0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * FG_SUBIN + 8; i += NT) subin[i] = 0.f;
+    for (int i = tid; i < CPAD; i += NT) { condin[i] = 0.f; c1[i] = 0.f; c2[i] = 0.f; }
+    for (int i = tid; i < FG_PREV; i += NT)
+        prev[i] = a.previous
+            ? a.previous[(size_t)(a.previous_batch == 1 ? 0 : b) * FG_PREV + i]
+            : 0.f;
+    int base = 0;   // ring offset of `prev`: logical i -> (base + i) % 512
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        // ---- frame: conditioning network (fargan.py:139-160) ----
+        const float* row = feat + (size_t)t * a.cstride;
+        if (tid < a.nfeat) condin[tid] = row[tid];
+        else if (tid < nin) condin[tid] = glob[tid - a.nfeat];
+        if (tid == 0) s_period = (int)rintf(row[a.nfeat]);   // fargan.py:94
+        __syncthreads();
+        {
+            part[tid] = fg_gemv<WT, 384, 2>(w.cond[0], condin, condin, CPAD, CPAD, tid);
+            __syncthreads();
+            if (tid < nin) c1[tid] = tanhf(part[tid] + part[tid + 384]);
+            __syncthreads();
+            part[tid] = fg_gemv<WT, 384, 2>(w.cond[1], c1, c1, CPAD, CPAD, tid);
+            __syncthreads();
+            if (tid < nin) c2[tid] = tanhf(part[tid] + part[tid + 384]);
+            __syncthreads();
+            if (tid < 512)
+                cond[tid] = tanhf(fg_gemv<WT, 512, 1>(w.cond[2], c2, c2, CPAD, CPAD, tid));
+            __syncthreads();
+        }
+        const int period = s_period;
+
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            // ---- sub-frame inputs (fargan.py:233-256) ----
+            if (tid < 128) {
+                subin[tid] = cond[4 * tid + s];          // reshape/permute :109
+            } else if (tid < 192) {
+                const int i = tid - 128;
+                const float v = prev[(base + FG_PREV - FG_SUB + i) & (FG_PREV - 1)];
+                subin[128 + i] = v;
+                skipbuf[1088 + i] = v;
+            } else if (tid < 260) {
+                const int i = tid - 192;
+                int idx = FG_PREV - period + i - 2;
+                if (idx >= FG_PREV) idx -= period;
+                idx = idx < 0 ? 0 : (idx >= FG_PREV ? FG_PREV - 1 : idx);
+                const float v = prev[(base + idx) & (FG_PREV - 1)];
+                subin[192 + i] = v;
+                if (i >= 2 && i < 66) skipbuf[1024 + i - 2] = v;
+            }
+            __syncthreads();
+
+            // ---- framewise conv: Linear(520 -> 256), tanh, GLU (:349-372) ----
+            part[tid] = fg_gemv<WT, 256, 3>(w.fwconv, subin, subin, 520, 520, tid);
+            __syncthreads();
+            if (tid < 256) f1[tid] = tanhf(part[tid] + part[tid + 256] + part[tid + 512]);
+            __syncthreads();
+            part[tid] = fg_gemv<WT, 256, 3>(w.fwconv_glu, f1, f1, 256, 256, tid);
+            __syncthreads();
+            if (tid < 256)
+                skipbuf[768 + tid] = f1[tid] * fg_sigmoid(
+                    part[tid] + part[tid + 256] + part[tid + 512]);
+            __syncthreads();
+
+            // ---- three GRU + GLU layers (:269-314) ----
+#pragma unroll 1
+            for (int n = 0; n < 3; ++n) {
+                // input [x | lookback | previous subframe]; x = fwconv output
+                // or the previous GLU output
+                const float* xa = n == 0 ? skipbuf + 768 : skipbuf + (n - 1) * 256;
+                part[tid] = fg_gemv<WT, 768, 1>(
+                    w.gru_ih[n], xa, skipbuf + 1024, 256, 384, tid);
+                part2[tid] = fg_gemv<WT, 768, 1>(
+                    w.gru_hh[n], hid[n], hid[n], 256, 256, tid);
+                __syncthreads();
+                if (tid < 256) {
+                    const float r = fg_sigmoid(part[tid] + part2[tid]);
+                    const float z = fg_sigmoid(part[256 + tid] + part2[256 + tid]);
+                    const float nn = tanhf(part[512 + tid] + r * part2[512 + tid]);
+                    hid[n][tid] = (1.f - z) * nn + z * hid[n][tid];
+                }
+                __syncthreads();
+                part[tid] = fg_gemv<WT, 256, 3>(w.gru_glu[n], hid[n], hid[n], 256, 256, tid);
+                __syncthreads();
+                if (tid < 256)
+                    skipbuf[n * 256 + tid] = hid[n][tid] * fg_sigmoid(
+                        part[tid] + part[tid + 256] + part[tid + 512]);
+                __syncthreads();
+            }
+
+            // ---- skip connection + output layer (:317-333) ----
+            part[tid] = fg_gemv<WT, 256, 3>(w.skip, skipbuf, skipbuf, FG_SKIP, FG_SKIP, tid);
+            __syncthreads();
+            if (tid < 256) f1[tid] = tanhf(part[tid] + part[tid + 256] + part[tid + 512]);
+            __syncthreads();
+            part[tid] = fg_gemv<WT, 256, 3>(w.skip_glu, f1, f1, 256, 256, tid);
+            __syncthreads();
+            if (tid < 256)
+                f1[tid] = f1[tid] * fg_sigmoid(
+                    part[tid] + part[tid + 256] + part[tid + 512]);
+            __syncthreads();
+            part[tid] = fg_gemv<WT, 64, 12>(w.out, f1, f1, 256, 256, tid);
+            __syncthreads();
+            if (tid < FG_SUB) {
+                float v = 0.f;
+#pragma unroll
+                for (int p = 0; p < 12; ++p) v += part[tid + 64 * p];
+                v = tanhf(v);
+                out[(size_t)t * FG_HOP + s * FG_SUB + tid] = v;
+                // the oldest 64 samples leave the window (fargan.py:122-129)
+                prev[(base + tid) & (FG_PREV - 1)] = v;
+            } else if (tid >= 256 && tid < 256 + FG_SUBIN) {
+                // states[3] <- this sub-frame's input (fargan.py:334)
+                subin[FG_SUBIN + tid - 256] = subin[tid - 256];
+            }
+            base = (base + FG_SUB) & (FG_PREV - 1);
+            __syncthreads();
+        }
+    }
+}

@@ -129,6 +129,7 @@ struct FeatureArgs {
     int rank_below, rank_above;  // torch.quantile(linear) gather indices
     float rank_weight;
     float fmin, fmax, min_db, db_range;
+    float period_rate;         // > 0: append SAMPLE_RATE / hz (FARGAN)
 };
 
 template <int THREADS>
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(THREADS) void pm_prepare_features_kernel(
     const int tx = threadIdx.x;
     const int T = a.T, P = a.P;
     if (t >= T) return;
-    const int C = P + a.E + a.bands + 1;
+    const int Cb = P + a.E + a.bands + 1;
+    const int C = Cb + (a.period_rate > 0.f ? 1 : 0);
     float* ocl = a.out_cl ? a.out_cl + ((size_t)b * T + t) * a.Cpad : nullptr;
     float* oref = a.out_ref ? a.out_ref + (size_t)b * C * T + t : nullptr;
 
@@ -211,11 +213,17 @@ __global__ __launch_bounds__(THREADS) void pm_prepare_features_kernel(
 
     // --- periodicity (:187-188) + zero channel padding ---
     const float per = a.periodicity[(size_t)b * T + t];
+    // pitch period in samples for the FARGAN lookback (generator.py:191-195)
+    const float period = a.period_rate > 0.f ? a.period_rate / hz : 0.f;
     if (ocl) {
-        ocl[C - 1] = per;
+        ocl[Cb - 1] = per;
+        if (C > Cb) ocl[Cb] = period;
         for (int i = C; i < a.Cpad; ++i) ocl[i] = 0.f;
     }
-    if (oref) oref[(size_t)(C - 1) * T] = per;
+    if (oref) {
+        oref[(size_t)(Cb - 1) * T] = per;
+        if (C > Cb) oref[(size_t)Cb * T] = period;
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -1,3 +1,4 @@
 from .core import get_padding
+from .fargan import FARGAN
 from .generator import Generator
 from .hifigan import HiFiGAN

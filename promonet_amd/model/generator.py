@@ -10,6 +10,7 @@ import torch
 
 import promonet_amd
 from promonet_amd import _lib
+from .fargan import FARGAN
 from .hifigan import HiFiGAN
 
 
@@ -17,14 +18,23 @@ class Generator(torch.nn.Module):
 
     def __init__(self):
         super().__init__()
-        if promonet_amd.MODEL != 'hifigan':
+        # Model selection (generator.py:18-31)
+        self.fargan = promonet_amd.MODEL == 'fargan'
+        if promonet_amd.MODEL == 'fargan':
+            self.model = FARGAN(
+                promonet_amd.NUM_FEATURES, promonet_amd.GLOBAL_CHANNELS)
+        elif promonet_amd.MODEL == 'hifigan':
+            self.model = HiFiGAN(
+                promonet_amd.NUM_FEATURES, promonet_amd.GLOBAL_CHANNELS)
+        else:
             raise ValueError(
-                f'Generator model {promonet_amd.MODEL} is not defined '
-                '(promonet_amd implements the hifigan hot path)')
+                f'Generator model {promonet_amd.MODEL} is not defined')
         if promonet_amd.ZERO_SHOT:
             raise ValueError('ZERO_SHOT speaker embeddings are not supported')
-        self.model = HiFiGAN(
-            promonet_amd.NUM_FEATURES, promonet_amd.GLOBAL_CHANNELS)
+        if not (promonet_amd.AUGMENT_PITCH and promonet_amd.AUGMENT_LOUDNESS):
+            raise ValueError(
+                'only the default global features (speaker + 2 ratios) are '
+                'supported')
 
         # generator.py:35-42, 92-95: torch.nn.Embedding default init N(0, 1)
         self.speaker_embedding = torch.nn.Embedding(
@@ -63,6 +73,11 @@ class Generator(torch.nn.Module):
             loudness, pitch, periodicity, ppg, channels_last=True)
         global_features = self.prepare_global_features(
             speakers, spectral_balance_ratios, loudness_ratios)
+        if self.fargan:
+            if previous_samples is None:
+                previous_samples = self.default_previous_samples
+            return self.model.forward_channels_last(
+                features_cl, global_features, previous_samples)
         return self.model.forward_channels_last(features_cl, global_features)
 
     def prepare_features(self, loudness, pitch, periodicity, ppg):
@@ -87,7 +102,7 @@ class Generator(torch.nn.Module):
             raise ValueError('feature shapes disagree')
         total = (
             channels + promonet_amd.PITCH_EMBEDDING_SIZE +
-            promonet_amd.LOUDNESS_BANDS + 1)
+            promonet_amd.LOUDNESS_BANDS + 1 + int(self.fargan))
         device = pitch.device
         edges = self.pitch_distribution.to(torch.float32).contiguous()
         table = self.pitch_embedding.weight.detach().to(
@@ -109,7 +124,9 @@ class Generator(torch.nn.Module):
                 promonet_amd.LOUDNESS_BANDS, cpad,
                 float(np.float32(self.ppg_threshold.item())),
                 promonet_amd.FMIN, promonet_amd.FMAX, promonet_amd.MIN_DB,
-                promonet_amd.REF_DB, _lib.stream()))
+                promonet_amd.REF_DB,
+                float(promonet_amd.SAMPLE_RATE) if self.fargan else 0.,
+                _lib.stream()))
         return out
 
     def prepare_global_features(

@@ -33,3 +33,9 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='session')
+def golden_fargan():
+    import torch
+    return torch.load(GOLDEN / 'generator_fargan.pt', weights_only=False)

@@ -174,3 +174,36 @@ def test_loudness_host_helpers():
     assert torch.allclose(
         promonet_amd.preprocess.spectrogram.mel_basis(), oracle.mel_basis(),
         atol=1e-8)
+
+
+def test_fargan_state_dict_contract(golden_fargan):
+    try:
+        promonet_amd.configure(MODEL='fargan')
+        assert promonet_amd.NUM_PREVIOUS_SAMPLES == \
+            golden_fargan['num_previous_samples'] == 512
+        model = promonet_amd.model.Generator()
+    finally:
+        promonet_amd.configure(MODEL='hifigan')
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert mine == golden_fargan['state_keys']
+    assert sum(p.numel() for p in model.model.parameters()) == 2_714_642 \
+        or sum(p.numel() for p in model.parameters()) > 2_700_000
+    # orthogonal init (fargan.py:418-424)
+    w = model.model.state_dict()['conditioning_network.0.weight']
+    assert torch.allclose(w @ w.T, torch.eye(371), atol=1e-4)
+    assert promonet_amd.NUM_PREVIOUS_SAMPLES == 1
+
+
+def test_fargan_engine_validation():
+    import ctypes
+    library = _lib.lib()
+    handle = ctypes.c_void_p()
+    assert library.pm_fargan_create(113, 258, _lib.PM_F32,
+                                    ctypes.byref(handle)) == 0
+    assert library.pm_fargan_finalize(handle, None) == -2
+    assert b'conditioning_network.0' in library.pm_last_error()
+    assert library.pm_fargan_destroy(handle) == 0
+    assert library.pm_fargan_create(80, 258, _lib.PM_F32,
+                                    ctypes.byref(handle)) == -1
+    assert library.pm_fargan_create(113, 258, _lib.PM_BF16,
+                                    ctypes.byref(handle)) == -1

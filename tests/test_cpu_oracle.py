@@ -135,3 +135,19 @@ def test_unpinned_third_party_sanity():
     full = oracle.loudness(audio, None)
     assert full.shape == (513, 12)
     assert max_abs(oracle.band_average(full, 8), loud) < 1e-5
+
+
+def test_fargan_golden(golden_fargan, golden_default):
+    """FARGAN restatement vs audio computed by the real reference
+    (config/fargan.py), incl. non-zero previous samples."""
+    state = oracle.random_state_fargan(seed=golden_fargan['seed'])
+    state['pitch_distribution'] = golden_default['pitch_distribution'].clone()
+    for name in ('b2_t8', 'b1_t60', 'b3_t25'):
+        entry = golden_fargan[name]
+        inputs = oracle.synthetic_inputs(
+            entry['batch'], entry['frames'], seed=entry['input_seed'])
+        with torch.inference_mode():
+            audio = oracle.fargan_generator_forward(
+                *inputs, state, entry['previous'])
+        assert audio.shape == (entry['batch'], 1, entry['frames'] * 256)
+        assert max_abs(audio, entry['audio']) < 1e-6, name

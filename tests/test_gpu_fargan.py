@@ -1,0 +1,102 @@
+"""GPU parity of the FARGAN path (config/fargan.py) against goldens computed
+by the REAL reference and against the CPU oracle on longer sequences."""
+import pytest
+import torch
+
+import restatement as oracle
+from util import max_abs
+
+pytestmark = pytest.mark.gpu
+
+# fp32 math everywhere; f16 only changes the STORAGE of the streamed weights
+GATE = {'fp32': 5e-6, 'f16': 1e-2}
+
+
+@pytest.fixture()
+def fargan_model(golden_fargan, golden_default, device):
+    import promonet_amd
+    state = oracle.random_state_fargan(seed=golden_fargan['seed'])
+    state['pitch_distribution'] = golden_default['pitch_distribution'].clone()
+    models = {}
+
+    def build(dtype):
+        if dtype not in models:
+            promonet_amd.configure(MODEL='fargan', FARGAN_WEIGHT_DTYPE=dtype)
+            try:
+                model = promonet_amd.model.Generator()
+                model.load_state_dict(state)
+                models[dtype] = model.to(device).eval()
+            finally:
+                promonet_amd.configure(
+                    MODEL='hifigan', FARGAN_WEIGHT_DTYPE='fp32')
+        return models[dtype]
+    build.state = state
+    return build
+
+
+def on(device, inputs):
+    return [t.to(device) for t in inputs]
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'f16'])
+def test_matches_reference_golden(device, golden_fargan, fargan_model, dtype):
+    model = fargan_model(dtype)
+    for name in ('b2_t8', 'b1_t60', 'b3_t25'):
+        entry = golden_fargan[name]
+        inputs = oracle.synthetic_inputs(
+            entry['batch'], entry['frames'], seed=entry['input_seed'])
+        with torch.inference_mode():
+            got = model(*on(device, inputs), entry['previous'].to(device))
+            features = model.prepare_features(*on(device, inputs[:4]))
+        assert got.shape == entry['audio'].shape
+        assert features.shape[1] == 114
+        assert max_abs(features[:, -1], entry['period']) < 1e-4
+        error = max_abs(got, entry['audio'])
+        print(f'fargan {dtype} {name}: max-abs {error:.3e} '
+              f'(abs-max {entry["audio"].abs().max().item():.3f})')
+        assert error < GATE[dtype], name
+
+
+def test_long_sequence_vs_oracle(device, fargan_model):
+    """Autoregression over 2 s (688 dependent steps) stays on the oracle's
+    trajectory; batch-1 previous samples / globals broadcast."""
+    model = fargan_model('fp32')
+    inputs = oracle.synthetic_inputs(2, 172, seed=9)
+    with torch.inference_mode():
+        want = oracle.fargan_generator_forward(*inputs, fargan_model.state)
+        got = model(*on(device, inputs), None)
+    assert got.shape == (2, 1, 172 * 256)
+    assert max_abs(got, want) < 2e-5
+
+
+def test_module_seam(device, fargan_model):
+    """FARGAN.forward(features (B,114,T), global (B,258,1), previous)."""
+    model = fargan_model('fp32')
+    inputs = oracle.synthetic_inputs(2, 12, seed=10)
+    state = fargan_model.state
+    features = oracle.prepare_features(
+        *inputs[:4], state['pitch_distribution'],
+        state['pitch_embedding.weight'], state['ppg_threshold'])
+    period = oracle.SAMPLE_RATE / torch.clip(inputs[1], 50., 550.)
+    features = torch.cat((features, period[:, None]), dim=1)
+    glob = oracle.prepare_global_features(
+        *inputs[4:7], state['speaker_embedding.weight'])
+    previous = torch.zeros(2, 1, 512)
+    want = oracle.fargan_forward(features, glob, previous, state)
+    with torch.inference_mode():
+        got = model.model(
+            features.to(device), glob.to(device), previous.to(device))
+    assert max_abs(got, want) < 5e-6
+    with pytest.raises(ValueError):
+        model.model(features[:, :-1].to(device), glob.to(device), None)
+
+
+def test_deterministic_and_batch_independent(device, fargan_model):
+    model = fargan_model('fp32')
+    inputs = on(device, oracle.synthetic_inputs(5, 40, seed=12))
+    with torch.inference_mode():
+        full = model(*inputs, None)
+        again = model(*inputs, None)
+        single = model(*[t[3:4] for t in inputs], None)
+    assert torch.equal(full, again)
+    assert torch.equal(single[0], full[3])
