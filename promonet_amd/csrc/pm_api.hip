@@ -612,10 +612,11 @@ static int forward_impl(
         }
         L *= st.r;
         const int si = xi;   // stage input is dead after the upsampler
-        const bool fuse_block = block3_enabled() && st.cout_pad <= 64 &&
+        const bool fuse_block = block3_enabled() && st.cout_pad <= 128 &&
                                 h->cfg.num_dilations <= 3;
         for (int j = 0; j < h->cfg.num_resblocks; ++j) {
             const int K = h->cfg.resblock_kernel_sizes[j];
+            bool fused = false;
             if (fuse_block) {
                 // whole Block (all dilations) in one kernel: U -> S
                 Block3Args a = {};
@@ -631,12 +632,16 @@ static int forward_impl(
                 a.B = B; a.L = L; a.mode = j == 0 ? 1 : 2; a.scale = scale;
                 char label[64];
                 snprintf(label, sizeof(label), "block_c%d_k%d", st.cout, K);
+                hipError_t e = hipSuccess;
                 PROF(h, s, label, flops,
                      (double)B * L * st.cout * 4 * (a.mode == 2 ? 3 : 2), {
-                    HIP_TRY(launch_block3(h->dtype, st.cout_pad, K, a, s));
+                    e = launch_block3(h->dtype, st.cout_pad, K, a, s);
+                    if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
                 });
-                continue;
+                fused = e == hipSuccess;
+                if (!fused && h->profile) h->marks.pop_back();
             }
+            if (fused) continue;
             const float* src = buf[ui];
             for (int n = 0; n < h->cfg.num_dilations; ++n) {
                 const bool last = n == h->cfg.num_dilations - 1;
@@ -843,7 +848,7 @@ extern "C" int pm_block_cl(
     if (!x || !out || !w1 || !b1 || !w2 || !b2 || !dilations || !ws)
         return fail(PM_EINVAL, "null argument");
     const int Cp = pad32(C);
-    if (Cp > 64) return fail(PM_EINVAL, "channels %d unsupported (<= 64)", C);
+    if (Cp > 128) return fail(PM_EINVAL, "channels %d unsupported (<= 128)", C);
     if ((K != 3 && K != 7 && K != 11) || niter < 1 || niter > 3)
         return fail(PM_EINVAL, "kernel %d / %d iterations unsupported", K, niter);
     if (ws_bytes < 3 * pm_op_workspace_bytes(C, C, K))
@@ -851,7 +856,7 @@ extern "C" int pm_block_cl(
     hipStream_t s = (hipStream_t)stream;
     ConvGeom g;
     g.mode = 0; g.cout = g.cin = C; g.k = K; g.cout_pad = g.cin_pad = g.M = Cp;
-    g.kt = K; g.ch = Cp;
+    g.kt = K; g.ch = Cp < 64 ? Cp : 64;
     Block3Args a = {};
     a.x = x; a.out = out; a.niter = niter; a.B = B; a.L = L; a.mode = mode;
     a.scale = scale;

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
     char* xbuf = smem;
     char* inter = smem + (NCH > 1 ? 2 : 1) * XR * SX;
 
-    const float* xb = a.x + (size_t)b * L * C;
+    const float* __restrict__ xb = a.x + (size_t)b * L * C;
     const int t_first = t0 - H2 - hd;
 
     floatx16 acc[MTW][NTW];
@@ -335,7 +335,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
 
     PM_STAMP(a, 4);
     // ---------------- epilogue 2: bias + residual (+ MRF accumulate) -------
-    float* ob = a.out + (size_t)b * L * C;
+    // All global loads of a 32x32 tile are issued before its first store:
+    // interleaved, every load queued behind the previous store's address
+    // dependence and the epilogue became 16 serial HBM round trips.
+    float* __restrict__ ob = a.out + (size_t)b * L * C;
+    const int mode = a.mode;
+    const float scale = a.scale;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         const int co_base = (wm * MTW + mt) * 32 + 4 * lh;
@@ -344,29 +349,34 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
             const int n = (wn * NTW + nt) * 32 + ln;
             const int t = t0 + n;
             if (n < TL && t < L) {
+                float4 bias[4], res[4], old[4];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int co = co_base + 8 * g4;
-                    const float4 bias =
-                        *reinterpret_cast<const float4*>(a.b2 + co);
-                    const float4 res = *reinterpret_cast<const float4*>(
+                    bias[g4] = *reinterpret_cast<const float4*>(a.b2 + co);
+                    res[g4] = *reinterpret_cast<const float4*>(
                         xb + (size_t)t * C + co);
+                    if (mode == 2)
+                        old[g4] = *reinterpret_cast<const float4*>(
+                            ob + (size_t)t * C + co);
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = co_base + 8 * g4;
                     float4 v;
-                    v.x = acc[mt][nt][4 * g4 + 0] + bias.x + res.x;
-                    v.y = acc[mt][nt][4 * g4 + 1] + bias.y + res.y;
-                    v.z = acc[mt][nt][4 * g4 + 2] + bias.z + res.z;
-                    v.w = acc[mt][nt][4 * g4 + 3] + bias.w + res.w;
-                    float4* dst =
-                        reinterpret_cast<float4*>(ob + (size_t)t * C + co);
-                    if (a.mode == 1) {
-                        v.x *= a.scale; v.y *= a.scale;
-                        v.z *= a.scale; v.w *= a.scale;
-                    } else if (a.mode == 2) {
-                        const float4 o = *dst;
-                        v.x = o.x + v.x * a.scale; v.y = o.y + v.y * a.scale;
-                        v.z = o.z + v.z * a.scale; v.w = o.w + v.w * a.scale;
+                    v.x = acc[mt][nt][4 * g4 + 0] + bias[g4].x + res[g4].x;
+                    v.y = acc[mt][nt][4 * g4 + 1] + bias[g4].y + res[g4].y;
+                    v.z = acc[mt][nt][4 * g4 + 2] + bias[g4].z + res[g4].z;
+                    v.w = acc[mt][nt][4 * g4 + 3] + bias[g4].w + res[g4].w;
+                    if (mode == 1) {
+                        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                    } else if (mode == 2) {
+                        v.x = old[g4].x + v.x * scale;
+                        v.y = old[g4].y + v.y * scale;
+                        v.z = old[g4].z + v.z * scale;
+                        v.w = old[g4].w + v.w * scale;
                     }
-                    *dst = v;
+                    *reinterpret_cast<float4*>(ob + (size_t)t * C + co) = v;
                 }
             }
         }
@@ -560,7 +570,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Whole `Block` fused (small channel counts, C <= 64): all 3 iterations of
+// Whole `Block` fused (where the +-6 (k-1) halo is affordable): all 3 iterations of
 //   x <- x + conv2(lrelu(conv1(lrelu(x))))            hifigan.py:198-210
 // in one kernel. The fp32 trunk x lives in REGISTERS (MFMA C/D layout, each
 // wave owns a run of time columns x a 32-channel slab), LDS only holds the two
@@ -596,8 +606,9 @@ template <class ET, int C, int K, int WM, int WN, int NTW>
 __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
     Block3Args a) {
     typedef typename ET::frag_t frag_t;
-    static_assert(C == 32 || C == 64, "block3 kernel is for C <= 64");
-    constexpr int KC = C / 16;
+    constexpr int CH = C < 64 ? C : 64;    // weight-stream chunk (as packed)
+    constexpr int NCH = C / CH;
+    constexpr int KC = CH / 16;
     constexpr int MTW = (C / 32) / WM;     // M tiles per wave
     constexpr int NC = WN * NTW * 32;      // columns held by the workgroup
     constexpr int NT = WM * WN * 64;
@@ -607,7 +618,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
     constexpr int ROWS_A = NC + 2 * MA;
     constexpr int ROWS_T = NC + 2 * H2;
     constexpr int G = (ET::ESZ == 4) ? 2 : KC;
-    constexpr int W_MT_STRIDE = K * KC * 64;
+    constexpr int W_CHUNK = K * KC * 64;
+    constexpr int W_MT_STRIDE = NCH * W_CHUNK;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* abuf = smem;
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
     const int b = wg / a.ntiles;
     const int L = a.L;
     const int c_first = tile * a.TL - a.halo;   // time of column 0
-    const float* xb = a.x + (size_t)b * L * C;
+    const float* __restrict__ xb = a.x + (size_t)b * L * C;
 
     // ---- zero the margins (they stand for neighbours' columns: only ever
     // feed the recomputed halo, but must be finite) ------------------------
@@ -644,18 +656,36 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
         }
     }
     // ---- stage a = lrelu(x) (coalesced), zero outside the utterance ------
+    // loads first, LDS writes after: a load-use-per-iteration loop is one
+    // HBM round trip per iteration
     {
         constexpr int Q = C / 4;
-        for (int i = tid; i < NC * Q; i += NT) {
-            const int col = i / Q, q = i % Q;
-            const int t = c_first + col;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < L)
-                v = *reinterpret_cast<const float4*>(
-                    xb + (size_t)t * C + q * 4);
-            v.x = pm_lrelu(v.x); v.y = pm_lrelu(v.y);
-            v.z = pm_lrelu(v.z); v.w = pm_lrelu(v.w);
-            ET::store4(abuf + (MA + col) * S + q * 4 * ET::ESZ, v);
+        constexpr int ITER = (NC * Q + NT - 1) / NT;
+        constexpr int BATCH = ITER < 12 ? ITER : 12;
+#pragma unroll 1
+        for (int i0 = 0; i0 < ITER; i0 += BATCH) {
+            float4 v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int i = tid + (i0 + u) * NT;
+                const int col = i / Q, q = i % Q;
+                const int t = c_first + col;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i0 + u < ITER && col < NC && t >= 0 && t < L)
+                    v[u] = *reinterpret_cast<const float4*>(
+                        xb + (size_t)t * C + q * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int i = tid + (i0 + u) * NT;
+                const int col = i / Q, q = i % Q;
+                if (i0 + u < ITER && col < NC) {
+                    float4 w4 = v[u];
+                    w4.x = pm_lrelu(w4.x); w4.y = pm_lrelu(w4.y);
+                    w4.z = pm_lrelu(w4.z); w4.w = pm_lrelu(w4.w);
+                    ET::store4(abuf + (MA + col) * S + q * 4 * ET::ESZ, w4);
+                }
+            }
         }
     }
     // ---- trunk registers <- x in the MFMA C/D layout ----------------------
@@ -704,9 +734,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
             for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-        mma_taps<ET, K, KC, MTW, NTW, G, S>(
-            acc, abuf + (MA - H2 * d) * S + col_off, d * S, w1, W_MT_STRIDE,
-            afirst, w2);
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c)
+            mma_taps<ET, K, KC, MTW, NTW, G, S>(
+                acc, abuf + (MA - H2 * d) * S + col_off + c * CH * ET::ESZ,
+                d * S, w1 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
+                c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -734,11 +767,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
 
         // ---- conv2 (dilation 1) out of `t`, residual into the trunk ----
         const bool last = it + 1 == a.niter;
-        mma_taps<ET, K, KC, MTW, NTW, G, S>(
-            acc, tbuf + col_off, S, w2, W_MT_STRIDE, afirst,
-            last ? nullptr
-                 : reinterpret_cast<const frag_t*>(a.w1[it + 1]) +
-                       (size_t)(wm * MTW) * W_MT_STRIDE + lane);
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c)
+            mma_taps<ET, K, KC, MTW, NTW, G, S>(
+                acc, tbuf + col_off + c * CH * ET::ESZ, S,
+                w2 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
+                c + 1 < NCH
+                    ? w2 + (size_t)(c + 1) * W_CHUNK
+                    : (last ? nullptr
+                            : reinterpret_cast<const frag_t*>(a.w1[it + 1]) +
+                                  (size_t)(wm * MTW) * W_MT_STRIDE + lane));
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -772,7 +810,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
     }
 
     // ---- store the valid interior (+ MRF accumulate) ----------------------
-    float* ob = a.out + (size_t)b * L * C;
+    float* __restrict__ ob = a.out + (size_t)b * L * C;
+    const int mode = a.mode;
+    const float scale = a.scale;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -780,6 +820,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
             const int col = (wn * NTW + nt) * 32 + ln;
             const int t = c_first + col;
             if (col >= a.halo && col < a.halo + a.TL && t < L) {
+                float4 old[4];
+                if (mode == 2) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        old[g4] = *reinterpret_cast<const float4*>(
+                            ob + (size_t)t * C + m_first + mt * 32 + 8 * g4 +
+                            4 * lh);
+                }
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int co = m_first + mt * 32 + 8 * g4 + 4 * lh;
@@ -788,17 +836,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
                     v.y = trunk[mt][nt][4 * g4 + 1];
                     v.z = trunk[mt][nt][4 * g4 + 2];
                     v.w = trunk[mt][nt][4 * g4 + 3];
-                    float4* dst =
-                        reinterpret_cast<float4*>(ob + (size_t)t * C + co);
-                    if (a.mode == 1) {
-                        v.x *= a.scale; v.y *= a.scale;
-                        v.z *= a.scale; v.w *= a.scale;
-                    } else if (a.mode == 2) {
-                        const float4 o = *dst;
-                        v.x = o.x + v.x * a.scale; v.y = o.y + v.y * a.scale;
-                        v.z = o.z + v.z * a.scale; v.w = o.w + v.w * a.scale;
+                    if (mode == 1) {
+                        v.x *= scale; v.y *= scale;
+                        v.z *= scale; v.w *= scale;
+                    } else if (mode == 2) {
+                        v.x = old[g4].x + v.x * scale;
+                        v.y = old[g4].y + v.y * scale;
+                        v.z = old[g4].z + v.z * scale;
+                        v.w = old[g4].w + v.w * scale;
                     }
-                    *dst = v;
+                    *reinterpret_cast<float4*>(ob + (size_t)t * C + co) = v;
                 }
             }
         }

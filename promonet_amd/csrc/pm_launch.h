@@ -95,16 +95,32 @@ int pm_pair_tile_len(int C, int K) {
 }
 
 // ---- whole-Block fusion ---------------------------------------------------
-template <class ET, int C> struct Block3Cfg;
-template <> struct Block3Cfg<ElemF16, 32> { enum { WM = 1, WN = 8, NTW = 3 }; };
-template <> struct Block3Cfg<ElemF16, 64> { enum { WM = 2, WN = 4, NTW = 4 }; };
-template <int C> struct Block3Cfg<ElemBF16, C> : Block3Cfg<ElemF16, C> {};
-template <> struct Block3Cfg<ElemF32, 32> { enum { WM = 1, WN = 8, NTW = 2 }; };
-template <> struct Block3Cfg<ElemF32, 64> { enum { WM = 2, WN = 4, NTW = 2 }; };
+// Geometry per (operand type, C, K). WM == 0: no whole-Block instantiation
+// (the caller runs one pair kernel per iteration instead). Measured: halving
+// the column count so that two workgroups share a CU is SLOWER (C = 64 k 3:
+// 1.65 vs 1.22 ms), so every shape takes the widest tile LDS allows.
+template <class ET, int C, int K> struct Block3Cfg { enum { WM = 0, WN = 1, NTW = 1 }; };
+template <> struct Block3Cfg<ElemF16, 32, 3>   { enum { WM = 1, WN = 8, NTW = 3 }; };
+template <> struct Block3Cfg<ElemF16, 32, 7>   { enum { WM = 1, WN = 8, NTW = 3 }; };
+template <> struct Block3Cfg<ElemF16, 32, 11>  { enum { WM = 1, WN = 8, NTW = 3 }; };
+template <> struct Block3Cfg<ElemF16, 64, 3>   { enum { WM = 2, WN = 4, NTW = 4 }; };
+template <> struct Block3Cfg<ElemF16, 64, 7>   { enum { WM = 2, WN = 4, NTW = 4 }; };
+template <> struct Block3Cfg<ElemF16, 64, 11>  { enum { WM = 2, WN = 4, NTW = 4 }; };
+template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 2, NTW = 4 }; };
+template <int C, int K> struct Block3Cfg<ElemBF16, C, K> : Block3Cfg<ElemF16, C, K> {};
+template <> struct Block3Cfg<ElemF32, 32, 3>   { enum { WM = 1, WN = 8, NTW = 2 }; };
+template <> struct Block3Cfg<ElemF32, 32, 7>   { enum { WM = 1, WN = 8, NTW = 2 }; };
+template <> struct Block3Cfg<ElemF32, 32, 11>  { enum { WM = 1, WN = 8, NTW = 2 }; };
+template <> struct Block3Cfg<ElemF32, 64, 3>   { enum { WM = 2, WN = 4, NTW = 2 }; };
+template <> struct Block3Cfg<ElemF32, 64, 7>   { enum { WM = 2, WN = 4, NTW = 2 }; };
+template <> struct Block3Cfg<ElemF32, 64, 11>  { enum { WM = 2, WN = 4, NTW = 2 }; };
 
 template <class ET, int C, int K>
 static hipError_t launch_block3_ck(const Block3Args& a0, hipStream_t stream) {
-    typedef Block3Cfg<ET, C> G;
+    typedef Block3Cfg<ET, C, K> G;
+    if constexpr (G::WM == 0) {
+        return hipErrorNotSupported;
+    } else {
     constexpr int WM = G::WM, WN = G::WN, NTW = G::NTW;
     constexpr int NC = WN * NTW * 32;
     Block3Args a = a0;
@@ -126,6 +142,7 @@ static hipError_t launch_block3_ck(const Block3Args& a0, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(a.ntiles * a.B), dim3(WM * WN * 64), smem,
                        stream, a);
     return hipGetLastError();
+    }
 }
 
 template <class ET, int C>
@@ -144,6 +161,7 @@ hipError_t pm_launch_block3(int C, int K, const Block3Args& a, hipStream_t s) {
         if (a.dil[i] < 1 || a.dil[i] > 5) return hipErrorNotSupported;
     if (a.niter < 1 || a.niter > 3) return hipErrorNotSupported;
     switch (C) {
+        case 128: return launch_block3_c<ET, 128>(K, a, s);
         case 64: return launch_block3_c<ET, 64>(K, a, s);
         case 32: return launch_block3_c<ET, 32>(K, a, s);
     }

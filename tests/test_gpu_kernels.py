@@ -112,7 +112,7 @@ def test_block_iteration_short_and_modes(device):
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
-@pytest.mark.parametrize('channels', [32, 64, 16])
+@pytest.mark.parametrize('channels', [32, 64, 16, 128])
 @pytest.mark.parametrize('kernel_size', [3, 7, 11])
 def test_whole_block(device, dtype, channels, kernel_size):
     """All three dilations of a Block fused in one kernel (trunk in
@@ -141,6 +141,8 @@ def test_whole_block(device, dtype, channels, kernel_size):
     def pointers(name):
         return (ctypes.c_void_p * 3)(*[t.data_ptr() for t in on_device[name]])
 
+    if channels == 128 and (kernel_size != 3 or dtype == 'fp32'):
+        pytest.skip('no whole-Block instantiation (halo too wide): pair path')
     dil = (ctypes.c_int * 3)(*dilations)
     ws = torch.empty(
         3 * _lib.lib().pm_op_workspace_bytes(channels, channels, kernel_size),
