@@ -85,6 +85,32 @@ static bool block3_enabled() {
     return enabled == 1;
 }
 
+static int pair_chunk(int dtype, int C) {
+    switch (dtype) {
+        case PM_F32: return pm_pair_chunk<ElemF32>(C);
+        case PM_F16: return pm_pair_chunk<ElemF16>(C);
+        case PM_BF16: return pm_pair_chunk<ElemBF16>(C);
+    }
+    return 0;
+}
+
+static bool block3_supported(int dtype, int C, int K) {
+    if (!block3_enabled()) return false;
+    switch (dtype) {
+        case PM_F32: return pm_block3_supported<ElemF32>(C, K);
+        case PM_F16: return pm_block3_supported<ElemF16>(C, K);
+        case PM_BF16: return pm_block3_supported<ElemBF16>(C, K);
+    }
+    return false;
+}
+
+// Chunk size the MRF conv weights of a (C, K) layer are packed with: the
+// whole-Block kernel streams 64-channel chunks, the pair kernel its own CH.
+static int mrf_chunk(int dtype, int C, int K, int ndil) {
+    if (ndil <= 3 && block3_supported(dtype, C, K)) return C < 64 ? C : 64;
+    return pair_chunk(dtype, C);
+}
+
 static hipError_t launch_single(
     int dtype, int kind, int ch, int cfg, const SingleArgs& a, hipStream_t s) {
     switch (dtype) {
@@ -296,7 +322,7 @@ extern "C" int pm_hifigan_create(
                     q.k = c->resblock_kernel_sizes[j];
                     q.cout_pad = q.cin_pad = q.M = s.cout_pad;
                     q.kt = q.k;
-                    q.ch = s.cout_pad < 64 ? s.cout_pad : 64;
+                    q.ch = mrf_chunk(h->dtype, s.cout_pad, q.k, c->num_dilations);
                 }
     }
     {
@@ -612,12 +638,11 @@ static int forward_impl(
         }
         L *= st.r;
         const int si = xi;   // stage input is dead after the upsampler
-        const bool fuse_block = block3_enabled() && st.cout_pad <= 128 &&
-                                h->cfg.num_dilations <= 3;
         for (int j = 0; j < h->cfg.num_resblocks; ++j) {
             const int K = h->cfg.resblock_kernel_sizes[j];
             bool fused = false;
-            if (fuse_block) {
+            if (h->cfg.num_dilations <= 3 &&
+                block3_supported(h->dtype, st.cout_pad, K)) {
                 // whole Block (all dilations) in one kernel: U -> S
                 Block3Args a = {};
                 a.x = buf[ui]; a.out = buf[si];
@@ -816,7 +841,7 @@ extern "C" int pm_block_iteration_cl(
     hipStream_t s = (hipStream_t)stream;
     ConvGeom g;
     g.mode = 0; g.cout = g.cin = C; g.k = K; g.cout_pad = g.cin_pad = g.M = Cp;
-    g.kt = K; g.ch = Cp < 64 ? Cp : 64;
+    g.kt = K; g.ch = pair_chunk(dtype, Cp);
     char* base = (char*)ws;
     const size_t wsz = align256((size_t)Cp * Cp * K * 4);
     void* p1 = base; void* p2 = base + wsz;

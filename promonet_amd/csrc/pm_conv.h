@@ -92,12 +92,20 @@ __device__ __forceinline__ void load_a_group(
 // `first` holds group 0 of this call's weight stream on entry (see
 // load_a_group); when `wnext` is non-null, group 0 of the NEXT call's stream
 // is fetched during the last group and returned in `first`.
-template <class ET, int KT, int KC, int MTW, int NTW, int G, int S>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `mid` runs once, half way through the groups: the place for work that only
+// needs loads issued before this call (they have landed by then: vmcnt retires
+// in order and every group waits on younger A loads) and whose VALU / LDS
+// writes should overlap the partner wave's MFMAs rather than sit between two
+// barriers - the fp32 -> operand conversion + LDS write of the next chunk.
+template <class ET, int KT, int KC, int MTW, int NTW, int G, int S,
+          class Hook = NoHook>
 __device__ __forceinline__ void mma_taps(
     floatx16 (&acc)[MTW][NTW], const char* bptr, const int tap_bytes,
     const typename ET::frag_t* __restrict__ wptr, const int w_mt_stride,
     typename ET::frag_t (&first)[G][MTW],
-    const typename ET::frag_t* __restrict__ wnext) {
+    const typename ET::frag_t* __restrict__ wnext, Hook mid = Hook()) {
     typedef typename ET::frag_t frag_t;
     constexpr int NS = KT * KC;
     static_assert(NS % G == 0, "group size must divide the step count");
@@ -127,6 +135,7 @@ __device__ __forceinline__ void mma_taps(
         } else if (wnext) {
             load_a_group<ET, MTW, G>(abuf[cur ^ 1], wnext, w_mt_stride);
         }
+        if (g0 == ((NS / G) / 2) * G) mid();
         // The fences pin the software pipeline. Left alone, the scheduler
         // sinks every load to just before its MFMA into ONE register set:
         // s_waitcnt vmcnt(0) (an L2 round trip) per A fragment and
@@ -198,19 +207,20 @@ struct PairGeom {
     static constexpr int TL = N1 - (K - 1);    // valid outputs per tile
 };
 
-template <class ET, int C, int K, int WM, int WN, int NTW>
+// ALIAS: the conv1 -> conv2 intermediate tile overlays the staged x chunks
+// (dead once every wave has finished conv1; costs one barrier).
+template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS>
 __host__ __device__ constexpr int pair_smem_bytes(int d) {
-    constexpr int CH = C < 64 ? C : 64;
     constexpr int NCH = C / CH;
     constexpr int N1 = WN * NTW * 32;
-    return (NCH > 1 ? 2 : 1) * (N1 + (K - 1) * d) * (CH * ET::ESZ + 16) +
-           (N1 + K - 1) * (C * ET::ESZ + 16);
+    const int x = (NCH > 1 ? 2 : 1) * (N1 + (K - 1) * d) * (CH * ET::ESZ + 16);
+    const int inter = (N1 + K - 1) * (C * ET::ESZ + 16);
+    return ALIAS ? (x > inter ? x : inter) : x + inter;
 }
 
-template <class ET, int C, int K, int WM, int WN, int NTW>
+template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS>
 __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
     typedef typename ET::frag_t frag_t;
-    constexpr int CH = C < 64 ? C : 64;
     constexpr int NCH = C / CH;
     constexpr int KC = CH / 16;
     constexpr int MT = C / 32;
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
     constexpr int SX = CH * ET::ESZ + 16;
     constexpr int SI = C * ET::ESZ + 16;
     constexpr int XR_MAX = N1 + (K - 1) * 5;
-    constexpr int G = (ET::ESZ == 4) ? (KC >= 2 ? 2 : 1) : KC;
+    constexpr int G = (ET::ESZ == 4) ? (KC >= 2 ? 2 : 1) : (KC < 4 ? KC : 4);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
     const int XR = N1 + (K - 1) * d;
 
     char* xbuf = smem;
-    char* inter = smem + (NCH > 1 ? 2 : 1) * XR * SX;
+    char* inter = ALIAS ? smem : smem + (NCH > 1 ? 2 : 1) * XR * SX;
 
     const float* __restrict__ xb = a.x + (size_t)b * L * C;
     const int t_first = t0 - H2 - hd;
@@ -278,15 +288,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
         char* cur = xbuf + (NCH > 1 ? (c & 1) * XR * SX : 0);
-        if (c + 1 < NCH) stager.load(xb, C, (c + 1) * CH, t_first, XR, L, tid);
+        const bool more = c + 1 < NCH;
+        if (more) stager.load(xb, C, (c + 1) * CH, t_first, XR, L, tid);
+        char* nxt = xbuf + ((c + 1) & 1) * XR * SX;
+        auto stage_next = [&]() {
+            if (more) stager.template store<true>(nxt, XR, tid);
+        };
+#ifdef PM_NO_MIDSTORE   // A/B experiment: staging store between the barriers
         mma_taps<ET, K, KC, MTW, NTW, G, SX>(
             acc, cur + lane_off_x, d * SX, w1 + (size_t)c * W_CHUNK,
-            W_MT_STRIDE, afirst,
-            c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
+            W_MT_STRIDE, afirst, more ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
+        stage_next();
+#else
+        mma_taps<ET, K, KC, MTW, NTW, G, SX>(
+            acc, cur + lane_off_x, d * SX, w1 + (size_t)c * W_CHUNK,
+            W_MT_STRIDE, afirst, more ? w1 + (size_t)(c + 1) * W_CHUNK : w2,
+            stage_next);
+#endif
         if (c < 2) PM_STAMP(a, 6 + 3 * c);
-        if (c + 1 < NCH) {
-            char* nxt = xbuf + ((c + 1) & 1) * XR * SX;
-            stager.template store<true>(nxt, XR, tid);
+        if (more) {
             if (c < 2) PM_STAMP(a, 7 + 3 * c);
             __syncthreads();
             if (c < 2) PM_STAMP(a, 8 + 3 * c);
@@ -294,6 +314,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(PairArgs a) {
     }
 
     PM_STAMP(a, 2);
+    if (ALIAS) __syncthreads();     // every wave is done with the x chunks
     // ---------------- epilogue 1: bias, lrelu, zero-pad mask -> LDS --------
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {

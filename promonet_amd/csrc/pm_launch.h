@@ -7,6 +7,10 @@
 template <class ET> hipError_t pm_launch_pair(
     int C, int K, const PairArgs& args, hipStream_t stream);
 template <class ET> int pm_pair_tile_len(int C, int K);
+// input-channel chunk size the pair kernel's weight stream is packed with
+template <class ET> int pm_pair_chunk(int C);
+// whether pm_launch_block3 has an instantiation for (C, K)
+template <class ET> bool pm_block3_supported(int C, int K);
 
 // Whole-Block fusion for C <= 64; returns hipErrorNotSupported when the shape
 // has no instantiation (caller falls back to the pair kernel).
@@ -29,26 +33,34 @@ template <class ET, int C> struct PairCfg;
 // memory path, not the matrix pipe, was the limiter at 2 loads per 4 MFMAs
 // (rocprof r01: MFMA busy 43 %). C = 128 takes 256-column tiles
 // (LDS 160,480 B at k 11, d 5).
-template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4 }; };
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4 }; };
-template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2 }; };
-template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1 }; };
+// CH: input channels staged per LDS chunk (one barrier per chunk). Measured:
+// CH = 128 (half the barriers, LDS tiles aliased) is 4 % slower than 64.
+template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 64, ALIAS = 0 }; };
+#ifdef PM_C128_SMALL   // A/B: half-size workgroups, two per CU
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 1, NTW = 4, CH = 64, ALIAS = 1 }; };
+#else
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0 }; };
+#endif
+template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
 template <int C> struct PairCfg<ElemBF16, C> : PairCfg<ElemF16, C> {};
 // exact fp32 operands: LDS rows are twice as wide -> 64-column tiles
-template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1 }; };
-template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1 }; };
-template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1 }; };
-template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1 }; };
+template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
 
 template <class ET, int C, int K>
 static hipError_t launch_pair_ck(const PairArgs& a0, hipStream_t stream) {
     typedef PairCfg<ET, C> G;
-    constexpr int WM = G::WM, WN = G::WN, NTW = G::NTW;
+    constexpr int WM = G::WM, WN = G::WN, NTW = G::NTW, CH = G::CH;
+    constexpr int ALIAS = G::ALIAS;
     constexpr int TL = WN * NTW * 32 - (K - 1);
     PairArgs a = a0;
     a.ntiles = (a.L + TL - 1) / TL;
-    auto kern = conv_pair_kernel<ET, C, K, WM, WN, NTW>;
-    const int smem = pair_smem_bytes<ET, C, K, WM, WN, NTW>(a.dilation);
+    auto kern = conv_pair_kernel<ET, C, K, WM, WN, NTW, CH, ALIAS>;
+    const int smem =
+        pair_smem_bytes<ET, C, K, WM, WN, NTW, CH, ALIAS>(a.dilation);
     static int max_set = 0;
     if (smem > max_set) {
         hipError_t e = hipFuncSetAttribute(
@@ -90,6 +102,17 @@ int pm_pair_tile_len(int C, int K) {
         case 128: return PairCfg<ET, 128>::WN * PairCfg<ET, 128>::NTW * 32 - (K - 1);
         case 64: return PairCfg<ET, 64>::WN * PairCfg<ET, 64>::NTW * 32 - (K - 1);
         case 32: return PairCfg<ET, 32>::WN * PairCfg<ET, 32>::NTW * 32 - (K - 1);
+    }
+    return 0;
+}
+
+template <class ET>
+int pm_pair_chunk(int C) {
+    switch (C) {
+        case 256: return PairCfg<ET, 256>::CH;
+        case 128: return PairCfg<ET, 128>::CH;
+        case 64: return PairCfg<ET, 64>::CH;
+        case 32: return PairCfg<ET, 32>::CH;
     }
     return 0;
 }
@@ -153,6 +176,26 @@ static hipError_t launch_block3_c(int K, const Block3Args& a, hipStream_t s) {
         case 11: return launch_block3_ck<ET, C, 11>(a, s);
     }
     return hipErrorNotSupported;
+}
+
+template <class ET, int C>
+static bool block3_supported_c(int K) {
+    switch (K) {
+        case 3: return Block3Cfg<ET, C, 3>::WM != 0;
+        case 7: return Block3Cfg<ET, C, 7>::WM != 0;
+        case 11: return Block3Cfg<ET, C, 11>::WM != 0;
+    }
+    return false;
+}
+
+template <class ET>
+bool pm_block3_supported(int C, int K) {
+    switch (C) {
+        case 128: return block3_supported_c<ET, 128>(K);
+        case 64: return block3_supported_c<ET, 64>(K);
+        case 32: return block3_supported_c<ET, 32>(K);
+    }
+    return false;
 }
 
 template <class ET>

@@ -54,6 +54,12 @@ class Generator(torch.nn.Module):
         self.register_buffer(
             'pitch_distribution', promonet_amd.load.pitch_distribution())
 
+        # host copy of the threshold: reading the buffer every forward would
+        # be a device sync (and is illegal inside a graph capture)
+        self._threshold = None
+        self.register_load_state_dict_post_hook(
+            lambda module, keys: setattr(module, '_threshold', None))
+
     ###########################################################################
     # Forward (generator.py:116-135)
     ###########################################################################
@@ -122,12 +128,17 @@ class Generator(torch.nn.Module):
                 out_cl, batch, frames, rows, channels,
                 promonet_amd.PITCH_BINS, promonet_amd.PITCH_EMBEDDING_SIZE,
                 promonet_amd.LOUDNESS_BANDS, cpad,
-                float(np.float32(self.ppg_threshold.item())),
+                self._host_threshold(),
                 promonet_amd.FMIN, promonet_amd.FMAX, promonet_amd.MIN_DB,
                 promonet_amd.REF_DB,
                 float(promonet_amd.SAMPLE_RATE) if self.fargan else 0.,
                 _lib.stream()))
         return out
+
+    def _host_threshold(self):
+        if self._threshold is None:
+            self._threshold = float(np.float32(self.ppg_threshold.item()))
+        return self._threshold
 
     def prepare_global_features(
         self,

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build an A/B variant of the library: scripts/build_variant.sh <suffix> <-DFLAGS...>
+# -> promonet_amd/lib/libpromonet_hip_<suffix>.so (select with PROMONET_HIP_LIB)
+set -e
+cd $(dirname $0)/..
+SUF=$1; shift
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-value $*"
+mkdir -p build/obj_$SUF
+for f in pm_api pm_conv_f16 pm_conv_bf16 pm_conv_f32; do
+  /opt/rocm/bin/hipcc $F -c promonet_amd/csrc/$f.hip -o build/obj_$SUF/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/obj_$SUF/*.o -o promonet_amd/lib/libpromonet_hip_$SUF.so
