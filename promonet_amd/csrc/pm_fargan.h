@@ -14,6 +14,9 @@
 #pragma once
 #include "pm_common.h"
 
+#ifndef FG_UNROLL
+#define FG_UNROLL 16
+#endif
 #define FG_THREADS 768
 #define FG_HOP 256
 #define FG_SUB 64
@@ -57,14 +60,18 @@ __device__ __forceinline__ float fg_gemv(
     const int b0 = part * blocks / PARTS, b1 = (part + 1) * blocks / PARTS;
     const int sb = split / VEC;
     const WT* wp = w + ((size_t)b0 * RPAD + row) * VEC;
-    float acc = 0.f;
-#pragma unroll 8
+    // FG_UNROLL independent 16-byte loads per thread in flight: the stream
+    // is latency-bound (weights exceed the 4 MB L2 of an XCD and come from
+    // the Infinity Cache), bytes in flight set the rate.
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll FG_UNROLL
     for (int b = b0; b < b1; ++b) {
         const float* x = b < sb ? xa + b * VEC : xb + (b - sb) * VEC;
-        acc += FgVec<WT>::dot(wp, x);
+        const float d = FgVec<WT>::dot(wp, x);
+        if (b & 1) acc1 += d; else acc0 += d;
         wp += (size_t)RPAD * VEC;
     }
-    return acc;
+    return acc0 + acc1;
 }
 
 // torch-layout W (rows, cols) fp32 -> [kpad / VEC][rpad][VEC], zero padded

@@ -35,30 +35,36 @@ template <class ET, int C> struct PairCfg;
 // (LDS 160,480 B at k 11, d 5).
 // CH: input channels staged per LDS chunk (one barrier per chunk). Measured:
 // CH = 128 (half the barriers, LDS tiles aliased) is 4 % slower than 64.
-template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 64, ALIAS = 0 }; };
-#ifdef PM_C128_SMALL   // A/B: half-size workgroups, two per CU
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 1, NTW = 4, CH = 64, ALIAS = 1 }; };
+#ifdef PM_LOADER_WAVES   // A/B: 4 extra waves own the activation staging
+template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 64, ALIAS = 0, LW = 4 }; };
 #else
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 64, ALIAS = 0, LW = 0 }; };
 #endif
-template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2, CH = 64, ALIAS = 0 }; };
-template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
+#ifdef PM_C128_SMALL   // A/B: half-size workgroups, two per CU
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 1, NTW = 4, CH = 64, ALIAS = 1, LW = 0 }; };
+#elif defined(PM_LOADER_WAVES)
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0, LW = 4 }; };
+#else
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0, LW = 0 }; };
+#endif
+template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2, CH = 64, ALIAS = 0, LW = 0 }; };
+template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0, LW = 0 }; };
 template <int C> struct PairCfg<ElemBF16, C> : PairCfg<ElemF16, C> {};
 // exact fp32 operands: LDS rows are twice as wide -> 64-column tiles
-template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
-template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
-template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
-template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0, LW = 0 }; };
+template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0, LW = 0 }; };
+template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1, CH = 64, ALIAS = 0, LW = 0 }; };
+template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0, LW = 0 }; };
 
 template <class ET, int C, int K>
 static hipError_t launch_pair_ck(const PairArgs& a0, hipStream_t stream) {
     typedef PairCfg<ET, C> G;
     constexpr int WM = G::WM, WN = G::WN, NTW = G::NTW, CH = G::CH;
-    constexpr int ALIAS = G::ALIAS;
+    constexpr int ALIAS = G::ALIAS, LW = G::LW;
     constexpr int TL = WN * NTW * 32 - (K - 1);
     PairArgs a = a0;
     a.ntiles = (a.L + TL - 1) / TL;
-    auto kern = conv_pair_kernel<ET, C, K, WM, WN, NTW, CH, ALIAS>;
+    auto kern = conv_pair_kernel<ET, C, K, WM, WN, NTW, CH, ALIAS, LW>;
     const int smem =
         pair_smem_bytes<ET, C, K, WM, WN, NTW, CH, ALIAS>(a.dilation);
     static int max_set = 0;
@@ -70,7 +76,8 @@ static hipError_t launch_pair_ck(const PairArgs& a0, hipStream_t stream) {
         max_set = smem;
     }
     const int grid = a.ntiles * a.B;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((WM * WN + LW) * 64), smem,
+                       stream, a);
     return hipGetLastError();
 }
 
