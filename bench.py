@@ -73,26 +73,41 @@ def cpu_baseline():
     fp32) timed on this host's cores on a bounded sample of the workload."""
     sys.path.insert(0, str(ROOT / 'oracle'))
     import restatement as oracle
-    batch, frames = 4, 430          # 4 x 5 s: ~10-30 s of CPU work
-    threads = torch.get_num_threads()
+    batch, frames = 4, 430          # 4 x 5 s of audio per run
     state = oracle.random_state(seed=0)
     inputs = oracle.synthetic_inputs(batch, frames, seed=1234)
-    times = []
-    with torch.inference_mode():
-        oracle.generator_forward(*inputs, state)           # warm-up
-        for _ in range(2):
-            start = time.perf_counter()
-            oracle.generator_forward(*inputs, state)
-            times.append(time.perf_counter() - start)
-    seconds = sorted(times)[len(times) // 2]
     samples = batch * frames * promonet_amd.HOPSIZE
+    cpus = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    # oneDNN does not scale to every core on this small a problem: time a few
+    # thread counts (bounded: ~10-30 s in total) and report the fastest
+    best = None
+    tried = {}
+    with torch.inference_mode():
+        for threads in sorted({min(t, cpus) for t in (16, 32, 64, default_threads)}):
+            torch.set_num_threads(threads)
+            oracle.generator_forward(*inputs, state)           # warm-up
+            times = []
+            for _ in range(2):
+                start = time.perf_counter()
+                oracle.generator_forward(*inputs, state)
+                times.append(time.perf_counter() - start)
+            seconds = min(times)
+            tried[threads] = samples / seconds
+            if best is None or seconds < best[1]:
+                best = (threads, seconds)
+    torch.set_num_threads(default_threads)
+    threads, seconds = best
     return {
         'value': samples / seconds, 'unit': 'samples/s', 'cores': threads,
         'kind': 'port',
         'rtf': samples / promonet_amd.SAMPLE_RATE / seconds,
-        'sample': f'oracle/restatement.py generator_forward, fp32, batch '
-                  f'{batch} x {frames} frames (5 s), median of 2 after 1 '
-                  f'warm-up, torch threads {threads} of {os.cpu_count()} cpus'}
+        'samples_per_s_by_threads': tried,
+        'sample': f'oracle/restatement.py generator_forward (PyTorch CPU port '
+                  f'of the reference op sequence), fp32, batch {batch} x '
+                  f'{frames} frames (5 s each), best of 2 after 1 warm-up at '
+                  f'the fastest of {sorted(tried)} torch threads on '
+                  f'{cpus} cpus'}
 
 
 def parse_profile(text):
@@ -173,7 +188,7 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         traffic = None
         traffic_file = ROOT / 'profiles' / 'traffic.json'
-        if traffic_file.exists():
+        if traffic_file.exists() and args.batch == 32 and frames == 861:
             traffic = json.loads(traffic_file.read_text()).get(
                 f'{label}:{args.dtype}')
         kernel_ms = sum(r['ms'] for r in profile.values()) / args.steps

@@ -35,12 +35,19 @@ template <class ET, int C> struct PairCfg;
 // (LDS 160,480 B at k 11, d 5).
 // CH: input channels staged per LDS chunk (one barrier per chunk). Measured:
 // CH = 128 (half the barriers, LDS tiles aliased) is 4 % slower than 64.
-#ifdef PM_LOADER_WAVES   // A/B: 4 extra waves own the activation staging
+#ifdef PM_C256_NARROW   // A/B: the previous 128-column tiles
+template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 64, ALIAS = 0, LW = 0 }; };
+#elif defined(PM_LOADER_WAVES)   // A/B: 4 extra waves own the activation staging
 template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 64, ALIAS = 0, LW = 4 }; };
 #else
-template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 64, ALIAS = 0, LW = 0 }; };
+// 192 columns per weight fetch (LDS tiles aliased to fit): the pair kernels
+// run at the power wall with the L2 94 % busy streaming weights, so fewer L2
+// bytes per MFMA is what buys clock (measured -7 % on k 7 / k 11).
+template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 6, CH = 64, ALIAS = 1, LW = 0 }; };
 #endif
-#ifdef PM_C128_SMALL   // A/B: half-size workgroups, two per CU
+#ifdef PM_C128_WIDE   // A/B: 384-column tiles
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 6, CH = 32, ALIAS = 1, LW = 0 }; };
+#elif defined(PM_C128_SMALL)   // A/B: half-size workgroups, two per CU
 template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 1, NTW = 4, CH = 64, ALIAS = 1, LW = 0 }; };
 #elif defined(PM_LOADER_WAVES)
 template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0, LW = 4 }; };

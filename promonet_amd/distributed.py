@@ -22,15 +22,18 @@ def init(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     use_gpu = torch.cuda.is_available()
-    device = torch.device(f'cuda:{local}' if use_gpu else 'cpu')
+    # one rank per GPU; the modulo only matters for smoke tests that put
+    # several ranks on a single-GPU box (PROMONET_DIST_BACKEND=gloo)
+    index = local % torch.cuda.device_count() if use_gpu else 0
+    device = torch.device(f'cuda:{index}' if use_gpu else 'cpu')
     if use_gpu:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group(
-            backend or ('nccl' if use_gpu else 'gloo'),
-            rank=rank, world_size=world)
+        backend = backend or os.environ.get('PROMONET_DIST_BACKEND') or (
+            'nccl' if use_gpu else 'gloo')
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 

@@ -72,6 +72,9 @@ class FARGAN(torch.nn.Module):
     # Engine lifetime
     ###########################################################################
 
+    def _invalidate(self):
+        self._destroy()
+
     def _destroy(self):
         if getattr(self, '_engine', None) is not None:
             _lib.lib().pm_fargan_destroy(self._engine)
