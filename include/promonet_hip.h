@@ -188,6 +188,16 @@ int pm_fold_weight_norm(const float* g, const float* v, float* w, int rows,
 int pm_to_channels_last(const float* src, float* dst, int batch, int channels,
                         int frames, int c_pad, void* stream);
 
+/* ---- feature editing: promonet.edit (edit/core.py:17-132) -----------------
+ * 1-D grid sampling (edit/grid.py:12-45) of `rows` sequences (rows, n_in) at
+ * the fractional frame positions grid (n_out) (NULL = identity), with the
+ * per-feature post-op fused: mode 0 linear, 1 linear in log2 then 2 ** y
+ * (pitch, core.py:114), 2 nearest; then y = clip(y * scale + offset, lo, hi)
+ * (pitch shift + clip core.py:121-125, loudness offset :128-129).          */
+int pm_grid_sample(const float* seq, const float* grid, float* out, int rows,
+                   int n_in, int n_out, int mode, float scale, float offset,
+                   float lo, float hi, void* stream);
+
 /* ---- FARGAN vocoder engine: replaces promonet.model.FARGAN ---------------
  * (promonet/model/fargan.py, selected by config/fargan.py MODEL = 'fargan').
  * One persistent workgroup per utterance; weight_dtype PM_F32 or PM_F16 is

@@ -168,6 +168,39 @@ def run(which):
         assert (dft - golden['spectrogram'][key].double().reshape(
             dft.shape)).abs().max() < 2e-5
 
+    # promonet.edit: grid.sample is reference code; the grid constructor is the
+    # stubbed third-party ppgs one (unpinned), so the grid is stored too
+    gen = torch.Generator().manual_seed(8)
+    frames = 37
+    edit_inputs = oracle.synthetic_inputs(1, frames, seed=13)
+    loud, pit, per, pg = (
+        edit_inputs[0][0], edit_inputs[1], edit_inputs[2], edit_inputs[3][0])
+    golden['edit'] = {'frames': frames, 'input_seed': 13, 'cases': []}
+    for cents, ratio, db in (
+        (None, 1.3, None), (200., None, None), (-700., .6, 3.5),
+        (None, None, -2.)
+    ):
+        result = promonet.edit.from_features(
+            loud.clone(), pit.clone(), per.clone(), pg.clone(), cents, ratio,
+            db, return_grid=True)
+        mine = oracle.edit_from_features(
+            loud.clone(), pit.clone(), per.clone(), pg.clone(), cents, ratio,
+            db, grid=result[4])
+        for a, b in zip(result[:4], mine):
+            assert a.shape == b.shape and (a - b).abs().max() < 1e-5
+        golden['edit']['cases'].append({
+            'pitch_shift_cents': cents, 'time_stretch_ratio': ratio,
+            'loudness_scale_db': db, 'grid': result[4],
+            'outputs': tuple(t.clone() for t in result[:4])})
+    sequence = torch.randn(3, 21, generator=gen)
+    grid = torch.rand(33, generator=gen) * 20.
+    golden['edit']['sample'] = {
+        'sequence': sequence, 'grid': grid,
+        'linear': promonet.edit.grid.sample(sequence, grid),
+        'nearest': promonet.edit.grid.sample(sequence, grid, 'nearest')}
+    assert (oracle.grid_sample(sequence, grid) -
+            golden['edit']['sample']['linear']).abs().max() < 1e-6
+
     # import-time constants the host mirror must reproduce
     golden['constants'] = {
         key: getattr(promonet, key) for key in (

@@ -138,6 +138,13 @@ def _install_stubs(config_files):
     for name in ('edit', 'load', 'preprocess', 'plot', 'data'):
         setattr(ppgs, name, mock.MagicMock())
         sys.modules[f'ppgs.{name}'] = getattr(ppgs, name)
+    # ppgs.edit.grid constructors used by promonet.edit (restated, unpinned)
+    def of_length(tensor, length):
+        return torch.linspace(0., tensor.shape[-1] - 1., int(length))
+
+    ppgs.edit.grid.of_length = of_length
+    ppgs.edit.grid.constant = lambda tensor, ratio: of_length(
+        tensor, round(tensor.shape[-1] / ratio + 1e-4))
     ppgs.from_audio = mock.MagicMock()
     ppgs.distance = mock.MagicMock()
 

@@ -701,3 +701,52 @@ def random_state_fargan(seed=0, pitch_distribution=None):
     state['pitch_embedding.weight'] = torch.randn(
         PITCH_BINS, PITCH_EMBEDDING_SIZE, generator=gen)
     return state
+
+
+
+###############################################################################
+# promonet.edit
+###############################################################################
+
+
+def grid_sample(sequence, grid, method='linear'):
+    """edit/grid.py:12-45 (PINNED against the reference by make_golden)."""
+    if method == 'linear':
+        xp = torch.arange(sequence.shape[-1])
+        i = torch.searchsorted(xp, grid, side='right')
+        fp = F.pad(sequence, (0, 1), mode='replicate')
+        xp = torch.cat((xp, xp[-1:] + 1))
+        return fp[..., i - 1] * (xp[i] - grid) + fp[..., i] * (grid - xp[i - 1])
+    if method == 'nearest':
+        return sequence[..., torch.round(grid).to(torch.long)]
+    raise ValueError(f'Grid sampling method {method} is not defined')
+
+
+def grid_of_length(tensor, length):
+    """`ppgs.edit.grid.of_length` (third-party, absent: PARITY UNPINNED)."""
+    return torch.linspace(0., tensor.shape[-1] - 1., int(length))
+
+
+def grid_constant(tensor, ratio):
+    """`ppgs.edit.grid.constant` (third-party, absent: PARITY UNPINNED)."""
+    return grid_of_length(tensor, round(tensor.shape[-1] / ratio + 1e-4))
+
+
+def edit_from_features(
+    loudness, pitch, periodicity, ppg, pitch_shift_cents=None,
+    time_stretch_ratio=None, loudness_scale_db=None, grid=None
+):
+    """edit/core.py:17-132 with stretch_unvoiced = stretch_silence = True."""
+    if time_stretch_ratio is not None:
+        if grid is None:
+            grid = grid_constant(ppg, time_stretch_ratio)
+        pitch = 2 ** grid_sample(torch.log2(pitch), grid)
+        periodicity = grid_sample(periodicity, grid)
+        loudness = grid_sample(loudness, grid)
+        ppg = grid_sample(ppg, grid, 'linear')
+    if pitch_shift_cents is not None:
+        pitch = torch.clip(
+            pitch.clone() * 2 ** (pitch_shift_cents / 1200), FMIN, FMAX)
+    if loudness_scale_db is not None:
+        loudness = loudness + loudness_scale_db
+    return loudness, pitch, periodicity, ppg

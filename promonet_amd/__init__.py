@@ -13,6 +13,7 @@ from .config import (                                          # noqa: F401
     LOG_FMIN, NUM_FEATURES, NUM_PREVIOUS_SAMPLES, NUM_SPEAKERS)
 from . import _lib                                             # noqa: F401
 from . import convert                                          # noqa: F401
+from . import edit                                             # noqa: F401
 from . import load                                             # noqa: F401
 from . import model                                            # noqa: F401
 from . import preprocess                                       # noqa: F401

@@ -30,6 +30,7 @@ PITCH_EMBEDDING = True
 PITCH_BINS = 256
 PITCH_EMBEDDING_SIZE = 64
 PPG_CHANNELS = 40
+PPG_INTERP_METHOD = 'linear'
 SPARSE_PPG_METHOD = 'percentile'
 SPARSE_PPG_THRESHOLD = 0.85
 SPECTROGRAM_ONLY = False

@@ -1100,6 +1100,22 @@ extern "C" int pm_loudness(
     return PM_OK;
 }
 
+// promonet.edit feature editing (edit/core.py:17-132, edit/grid.py:12-45)
+extern "C" int pm_grid_sample(
+    const float* seq, const float* grid, float* out, int rows, int n_in,
+    int n_out, int mode, float scale, float offset, float lo, float hi,
+    void* stream) {
+    if (!seq || !out) return fail(PM_EINVAL, "null argument");
+    if (rows < 1 || n_in < 1 || n_out < 1 || mode < 0 || mode > 2)
+        return fail(PM_EINVAL, "bad grid-sample arguments");
+    if (rows > 65535) return fail(PM_EINVAL, "too many rows (max 65535)");
+    hipLaunchKernelGGL(pm_grid_sample_kernel, dim3((n_out + 255) / 256, rows),
+                       dim3(256), 0, (hipStream_t)stream, seq, grid, out, rows,
+                       n_in, n_out, mode, scale, offset, lo, hi);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
 // ---------------------------------------------------------------------------
 // FARGAN engine (config/fargan.py): replaces promonet.model.FARGAN
 // ---------------------------------------------------------------------------

@@ -306,3 +306,41 @@ __global__ __launch_bounds__(THREADS) void pm_out_conv_kernel(
     }
     y[(size_t)b * L + t] = tanhf(acc);
 }
+
+// ---------------------------------------------------------------------------
+// promonet.edit: 1-D grid sampling of a frame
+// sequence (edit/grid.py:12-45) with the per-feature post-ops of
+// edit/core.py:114-127 fused: pitch is interpolated in log2 and re-exponent-
+// iated, shifted by a ratio and clipped; loudness gets a dB offset.
+//   mode 0: linear   y = a (fl + 1 - x) + b (x - fl), fl = floor(x),
+//                    b = seq[min(fl + 1, n - 1)]  (replicate pad, grid.py:27-35)
+//   mode 1: linear in log2, then 2 ** y            (core.py:114)
+//   mode 2: nearest  seq[round(x)]                 (grid.py:41-42)
+// then y = clip(y * scale + offset, lo, hi).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pm_grid_sample_kernel(
+    const float* __restrict__ seq, const float* __restrict__ grid,
+    float* __restrict__ out, int rows, int n_in, int n_out, int mode,
+    float scale, float offset, float lo, float hi) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (j >= n_out) return;
+    const float* s = seq + (size_t)r * n_in;
+    const float x = grid ? grid[j] : (float)j;
+    float y;
+    if (mode == 2) {
+        int i = (int)rintf(x);
+        i = i < 0 ? 0 : (i >= n_in ? n_in - 1 : i);
+        y = s[i];
+    } else {
+        int fl = (int)floorf(x);
+        fl = fl < 0 ? 0 : (fl >= n_in ? n_in - 1 : fl);
+        const int up = fl + 1 < n_in ? fl + 1 : n_in - 1;
+        float a = s[fl], b = s[up];
+        if (mode == 1) { a = log2f(a); b = log2f(b); }
+        y = a * ((float)(fl + 1) - x) + b * (x - (float)fl);
+        if (mode == 1) y = exp2f(y);
+    }
+    y = y * scale + offset;
+    out[(size_t)r * n_out + j] = fminf(fmaxf(y, lo), hi);
+}

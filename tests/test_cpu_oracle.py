@@ -151,3 +151,26 @@ def test_fargan_golden(golden_fargan, golden_default):
                 *inputs, state, entry['previous'])
         assert audio.shape == (entry['batch'], 1, entry['frames'] * 256)
         assert max_abs(audio, entry['audio']) < 1e-6, name
+
+
+def test_edit_golden(golden_default):
+    """promonet.edit restatement vs the real reference (grid from the golden:
+    its constructor is third-party ppgs)."""
+    entry = golden_default['edit']
+    inputs = oracle.synthetic_inputs(1, entry['frames'], seed=entry['input_seed'])
+    args = (inputs[0][0], inputs[1], inputs[2], inputs[3][0])
+    for case in entry['cases']:
+        got = oracle.edit_from_features(
+            *[t.clone() for t in args], case['pitch_shift_cents'],
+            case['time_stretch_ratio'], case['loudness_scale_db'],
+            grid=case['grid'])
+        for mine, want in zip(got, case['outputs']):
+            assert mine.shape == want.shape and max_abs(mine, want) < 1e-5
+        if case['grid'] is not None:
+            assert max_abs(oracle.grid_constant(
+                args[3], case['time_stretch_ratio']), case['grid']) == 0.
+    sample = entry['sample']
+    assert max_abs(oracle.grid_sample(
+        sample['sequence'], sample['grid']), sample['linear']) < 1e-6
+    assert max_abs(oracle.grid_sample(
+        sample['sequence'], sample['grid'], 'nearest'), sample['nearest']) == 0.

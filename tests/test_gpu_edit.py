@@ -1,0 +1,75 @@
+"""GPU parity of promonet_amd.edit against goldens computed by the real
+reference's `promonet.edit.from_features` / `promonet.edit.grid.sample`
+(the grid CONSTRUCTOR is third-party ppgs: stored in the golden)."""
+import pytest
+import torch
+
+import restatement as oracle
+from util import max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_grid_sample_golden(device, golden_default):
+    import promonet_amd
+    entry = golden_default['edit']['sample']
+    sequence, grid = entry['sequence'].to(device), entry['grid'].to(device)
+    assert max_abs(
+        promonet_amd.edit.grid.sample(sequence, grid), entry['linear']) < 1e-5
+    assert max_abs(
+        promonet_amd.edit.grid.sample(sequence, grid, 'nearest'),
+        entry['nearest']) == 0.
+    with pytest.raises(ValueError):
+        promonet_amd.edit.grid.sample(sequence, grid, 'cubic')
+
+
+def test_from_features_golden(device, golden_default):
+    import promonet_amd
+    entry = golden_default['edit']
+    inputs = oracle.synthetic_inputs(1, entry['frames'], seed=entry['input_seed'])
+    loud, pit, per, pg = (
+        inputs[0][0].to(device), inputs[1].to(device), inputs[2].to(device),
+        inputs[3][0].to(device))
+    for case in entry['cases']:
+        got = promonet_amd.edit.from_features(
+            loud, pit, per, pg, case['pitch_shift_cents'],
+            case['time_stretch_ratio'], case['loudness_scale_db'],
+            return_grid=True)
+        if case['grid'] is not None:
+            assert max_abs(got[4], case['grid']) < 1e-5
+        for mine, want, tolerance in zip(
+                got[:4], case['outputs'], (2e-4, 2e-3, 1e-5, 1e-5)):
+            assert mine.shape == want.shape
+            assert max_abs(mine, want) < tolerance, case
+    # inputs are never mutated (the reference's `loudness +=` is in place)
+    assert torch.equal(loud.cpu(), inputs[0][0])
+    with pytest.raises(NotImplementedError):
+        promonet_amd.edit.from_features(
+            loud, pit, per, pg, time_stretch_ratio=1.2, stretch_unvoiced=False)
+
+
+def test_edit_then_synthesize_stays_on_device(device, golden_default):
+    """README usage: edit -> synthesize without leaving the GPU."""
+    import promonet_amd
+    state = oracle.random_state(seed=0)
+    state['pitch_distribution'] = golden_default['pitch_distribution'].clone()
+    promonet_amd.configure(COMPUTE_DTYPE='fp32')
+    try:
+        model = promonet_amd.model.Generator()
+        model.load_state_dict(state)
+    finally:
+        promonet_amd.configure(COMPUTE_DTYPE='f16')
+    promonet_amd.synthesize.set_model(model, device)
+    inputs = oracle.synthetic_inputs(1, 30, seed=2)
+    args = [inputs[0][0], inputs[1], inputs[2], inputs[3][0]]
+    edited = promonet_amd.edit.from_features(
+        *[t.to(device) for t in args], pitch_shift_cents=300.,
+        time_stretch_ratio=1.5)
+    audio = promonet_amd.synthesize.from_features(
+        edited[0], edited[1], edited[2], edited[3][None], gpu=0)
+    want_features = oracle.edit_from_features(*args, 300., 1.5)
+    want = oracle.from_features(
+        want_features[0], want_features[1], want_features[2],
+        want_features[3][None], state)
+    assert audio.shape == want.shape == (1, 20 * 256)
+    assert max_abs(audio, want) < 1e-5
