@@ -108,6 +108,18 @@ int pm_hifigan_forward_cl(pm_hifigan_t h, const float* features_cl,
                           float* out, int batch, int frames, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Ragged batch (no reference counterpart: the reference synthesises one
+ * utterance per call, synthesize/core.py:158-201): lengths (B) int32 device
+ * array of valid frames <= frames; frames past an utterance's end are never
+ * read, so each utterance equals its stand-alone synthesis; the output tail
+ * is zero. features_cl != 0: features are channels-last (B, T, C_pad).     */
+int pm_hifigan_forward_ragged(pm_hifigan_t h, const float* features,
+                              int features_cl, const float* global_features,
+                              int global_batch, const int* lengths,
+                              float* out, int batch, int frames,
+                              void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 /* Optional per-launch timing (HIP events recorded on `stream` around every
  * kernel the forward launches; no reference counterpart - the reference only
  * has wall-clock torchutil timers, synthesize/core.py:222,250). collect()

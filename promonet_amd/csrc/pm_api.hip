@@ -569,7 +569,7 @@ extern "C" size_t pm_hifigan_workspace_bytes(pm_hifigan_t h, int B, int T) {
 static int forward_impl(
     pm_hifigan_t h, const float* features, bool features_cl, const float* g,
     int gbatch, float* out, int B, int T, void* ws, size_t ws_bytes,
-    hipStream_t s) {
+    hipStream_t s, const int* lengths = nullptr) {
     if (!h || !features || !g || !out || !ws)
         return fail(PM_EINVAL, "null argument");
     if (!h->finalized) return fail(PM_ESTATE, "pm_hifigan_finalize not called");
@@ -609,6 +609,7 @@ static int forward_impl(
         a.bias = h->in_conv.bias; a.gbias = gbias; a.gbias_batch = gbatch;
         a.B = B; a.L = T; a.Lout = T; a.Cin = h->cfp; a.M = h->c0p;
         a.lrelu = 0; a.pad = 3; a.phase_r = 0; a.phase_c = 1;
+        a.lengths = lengths; a.len_scale = 1;
         PROF(h, s, "input_conv",
              2.0 * h->c0 * h->cfg.num_features * 7 * B * T,
              (double)B * T * (h->cfg.num_features + h->c0) * 4, {
@@ -618,6 +619,7 @@ static int forward_impl(
     }
     int xi = 0;        // index of the buffer holding the stage input
     int L = T;
+    int rate = 1;      // samples per frame at the current stage
     const float scale = 1.f / (float)h->cfg.num_resblocks;
     for (auto& st : h->stages) {
         const int ui = (xi + 1) & 3, ai = (xi + 2) & 3, bi = (xi + 3) & 3;
@@ -628,6 +630,7 @@ static int forward_impl(
             a.B = B; a.L = L; a.Lout = L; a.Cin = st.cin_pad;
             a.M = st.up.geom.M; a.lrelu = 1; a.pad = 1;
             a.phase_c = st.cout_pad; a.phase_p = st.r / 2; a.phase_r = st.r;
+            a.lengths = lengths; a.len_scale = rate;
             char label[64];
             snprintf(label, sizeof(label), "convT_c%d_r%d", st.cin, st.r);
             PROF(h, s, label, 2.0 * st.cin * st.cout * st.k * B * L,
@@ -637,6 +640,7 @@ static int forward_impl(
             });
         }
         L *= st.r;
+        rate *= st.r;
         const int si = xi;   // stage input is dead after the upsampler
         for (int j = 0; j < h->cfg.num_resblocks; ++j) {
             const int K = h->cfg.resblock_kernel_sizes[j];
@@ -655,6 +659,7 @@ static int forward_impl(
                     flops += 4.0 * st.cout * st.cout * K * B * L;
                 }
                 a.B = B; a.L = L; a.mode = j == 0 ? 1 : 2; a.scale = scale;
+                a.lengths = lengths; a.len_scale = rate;
                 char label[64];
                 snprintf(label, sizeof(label), "block_c%d_k%d", st.cout, K);
                 hipError_t e = hipSuccess;
@@ -679,6 +684,7 @@ static int forward_impl(
                 a.dilation = h->cfg.resblock_dilations[j][n];
                 a.mode = last ? (j == 0 ? 1 : 2) : 0;
                 a.scale = scale;
+                a.lengths = lengths; a.len_scale = rate;
                 char label[64];
                 snprintf(label, sizeof(label), "pair_c%d_k%d", st.cout, K);
                 PROF(h, s, label, 4.0 * st.cout * st.cout * K * B * L,
@@ -698,7 +704,8 @@ static int forward_impl(
              (double)B * L * (h->c_last + 1) * 4, {
             hipLaunchKernelGGL(pm_out_conv_kernel<TH>,
                                dim3((L + TH - 1) / TH, B), dim3(TH), smem, s,
-                               buf[xi], h->out_w, out, L, C, h->c_last);
+                               buf[xi], h->out_w, out, L, C, h->c_last,
+                               lengths, rate);
             HIP_TRY(hipGetLastError());
         });
     }
@@ -762,6 +769,19 @@ extern "C" int pm_hifigan_forward_cl(
     float* out, int B, int T, void* ws, size_t ws_bytes, void* stream) {
     return forward_impl(h, features_cl, true, g, gbatch, out, B, T, ws,
                         ws_bytes, (hipStream_t)stream);
+}
+
+// Ragged batch: utterance b is lengths[b] <= T frames long inside the padded
+// (B, T, ...) tensors. Every kernel treats frames >= lengths[b] as outside
+// the sequence (the convolutions' zero padding), so out[b, :, :256 lengths[b]]
+// is bit-identical to synthesising utterance b alone; the tail is zeros.
+extern "C" int pm_hifigan_forward_ragged(
+    pm_hifigan_t h, const float* features, int features_cl, const float* g,
+    int gbatch, const int* lengths, float* out, int B, int T, void* ws,
+    size_t ws_bytes, void* stream) {
+    if (!lengths) return fail(PM_EINVAL, "null lengths");
+    return forward_impl(h, features, features_cl != 0, g, gbatch, out, B, T,
+                        ws, ws_bytes, (hipStream_t)stream, lengths);
 }
 
 // ---------------------------------------------------------------------------
@@ -944,7 +964,8 @@ extern "C" int pm_out_conv_tanh(
     constexpr int TH = 256;
     const size_t smem = ((size_t)(TH + 6) * (Cp + 1) + 7 * Cp) * sizeof(float);
     hipLaunchKernelGGL(pm_out_conv_kernel<TH>, dim3((L + TH - 1) / TH, B),
-                       dim3(TH), smem, (hipStream_t)stream, x, w, out, L, Cp, C);
+                       dim3(TH), smem, (hipStream_t)stream, x, w, out, L, Cp, C,
+                       (const int*)nullptr, 1);
     HIP_TRY(hipGetLastError());
     return PM_OK;
 }

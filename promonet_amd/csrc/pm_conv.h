@@ -198,6 +198,8 @@ struct PairArgs {
     int mode;            // 0: out = y; 1: out = y * scale; 2: out += y * scale
     float scale;
     int ntiles;          // tiles per utterance
+    const int* lengths;  // (B) valid frames per utterance or null (ragged batch)
+    int len_scale;       // samples of this tensor per frame
     unsigned long long* timeline;   // debug: 16 s_memtime stamps per block
 };
 
@@ -250,7 +252,11 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
     const int tile = wg % a.ntiles;
     const int b = wg / a.ntiles;
     const int t0 = tile * TL;
-    const int L = a.L;
+    // Ragged batches: utterance b is L rows long inside a (B, a.L, C) buffer;
+    // rows >= L are never read (they count as the conv's zero padding) nor
+    // written, so every utterance equals its stand-alone synthesis.
+    const int L = a.lengths ? min(a.lengths[b] * a.len_scale, a.L) : a.L;
+    if (t0 >= L) return;
     const int d = a.dilation;
     const int hd = H2 * d;
     const int XR = N1 + (K - 1) * d;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
     char* xbuf = smem;
     char* inter = ALIAS ? smem : smem + (NCH > 1 ? 2 : 1) * XR * SX;
 
-    const float* __restrict__ xb = a.x + (size_t)b * L * C;
+    const float* __restrict__ xb = a.x + (size_t)b * a.L * C;
     const int t_first = t0 - H2 - hd;
 
     floatx16 acc[MTW][NTW];
@@ -398,7 +404,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
     // All global loads of a 32x32 tile are issued before its first store:
     // interleaved, every load queued behind the previous store's address
     // dependence and the epilogue became 16 serial HBM round trips.
-    float* __restrict__ ob = a.out + (size_t)b * L * C;
+    float* __restrict__ ob = a.out + (size_t)b * a.L * C;
     const int mode = a.mode;
     const float scale = a.scale;
 #pragma unroll
@@ -466,6 +472,8 @@ struct SingleArgs {
     // phase_r == 0 disables (plain conv, window = all KT taps from 0)
     int phase_c, phase_p, phase_r;
     int ntiles, nmblocks;
+    const int* lengths;   // (B) valid frames per utterance or null
+    int len_scale;        // input rows per frame
 };
 
 // KT: taps contracted per M tile; KSPAN: taps spanned by the staged halo
@@ -506,13 +514,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
     const int tile = (wg / a.nmblocks) % a.ntiles;
     const int b = wg / (a.nmblocks * a.ntiles);
     const int t0 = tile * N1;
-    const int L = a.L, Cin = a.Cin, M = a.M;
+    const int Cin = a.Cin, M = a.M;
+    const int L = a.lengths ? min(a.lengths[b] * a.len_scale, a.L) : a.L;
+    const int Lout = a.lengths ? L : a.Lout;   // ragged: conv / convT only
+    if (t0 >= Lout) return;
     const int NCH = Cin / CH;
     const int m0 = mb * MB + wm * MTW * 32;   // this wave's first M row
     int js = 0;
     if (a.phase_r > 0 && (m0 / a.phase_c) + a.phase_p >= a.phase_r) js = 1;
 
-    const float* xb = a.x + (size_t)b * L * Cin;
+    const float* xb = a.x + (size_t)b * a.L * Cin;
     const int t_first = t0 - a.pad;
 
     floatx16 acc[MTW][NTW];
@@ -565,7 +576,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
         for (int nt = 0; nt < NTW; ++nt) {
             const int n = (wn * NTW + nt) * 32 + ln;
             const int t = t0 + n;
-            if (t < a.Lout) {
+            if (t < Lout) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int co = co_base + 8 * g4;
@@ -652,6 +663,8 @@ struct Block3Args {
     int mode;            // 0: out = y; 1: out = y * scale; 2: out += y * scale
     float scale;
     int ntiles, halo, TL;
+    const int* lengths;  // (B) valid frames per utterance or null
+    int len_scale;
     unsigned long long* timeline;   // debug: 16 s_memtime stamps per block
 };
 
@@ -695,9 +708,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
     const int wg = pm_xcd_remap(blockIdx.x, gridDim.x);
     const int tile = wg % a.ntiles;
     const int b = wg / a.ntiles;
-    const int L = a.L;
+    const int L = a.lengths ? min(a.lengths[b] * a.len_scale, a.L) : a.L;
+    if (tile * a.TL >= L) return;
     const int c_first = tile * a.TL - a.halo;   // time of column 0
-    const float* __restrict__ xb = a.x + (size_t)b * L * C;
+    const float* __restrict__ xb = a.x + (size_t)b * a.L * C;
 
     // ---- zero the margins (they stand for neighbours' columns: only ever
     // feed the recomputed halo, but must be finite) ------------------------
@@ -870,7 +884,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
     }
 
     // ---- store the valid interior (+ MRF accumulate) ----------------------
-    float* __restrict__ ob = a.out + (size_t)b * L * C;
+    float* __restrict__ ob = a.out + (size_t)b * a.L * C;
     const int mode = a.mode;
     const float scale = a.scale;
 #pragma unroll

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256) void pm_speaker_bias_kernel(
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void pm_out_conv_kernel(
     const float* __restrict__ x, const float* __restrict__ w,
-    float* __restrict__ y, int L, int C, int Cw) {
+    float* __restrict__ y, int Lmax, int C, int Cw,
+    const int* __restrict__ lengths, int len_scale) {
     extern __shared__ float sm[];
     constexpr int KW = 7, HALO = 3;
     const int S = C + 1;
@@ -279,7 +280,14 @@ __global__ __launch_bounds__(THREADS) void pm_out_conv_kernel(
     float* wsm = sm + (THREADS + 2 * HALO) * S;   // [KW][C]
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * THREADS;
-    const float* xb = x + (size_t)b * L * C;
+    // ragged batch: samples past the utterance's end are written as zeros
+    const int L = lengths ? min(lengths[b] * len_scale, Lmax) : Lmax;
+    if (t0 >= L) {
+        if (t0 + (int)threadIdx.x < Lmax)
+            y[(size_t)b * Lmax + t0 + threadIdx.x] = 0.f;
+        return;
+    }
+    const float* xb = x + (size_t)b * Lmax * C;
     for (int i = threadIdx.x; i < KW * C; i += THREADS) {
         const int j = i / C, c = i % C;
         wsm[i] = c < Cw ? w[c * KW + j] : 0.f;
@@ -297,14 +305,17 @@ __global__ __launch_bounds__(THREADS) void pm_out_conv_kernel(
     }
     __syncthreads();
     const int t = t0 + threadIdx.x;
-    if (t >= L) return;
+    if (t >= L) {
+        if (t < Lmax) y[(size_t)b * Lmax + t] = 0.f;
+        return;
+    }
     float acc = 0.f;
     for (int j = 0; j < KW; ++j) {
         const float* xr = xs + (threadIdx.x + j) * S;
         const float* wr = wsm + j * C;
         for (int c = 0; c < C; ++c) acc = fmaf(wr[c], xr[c], acc);
     }
-    y[(size_t)b * L + t] = tanhf(acc);
+    y[(size_t)b * Lmax + t] = tanhf(acc);
 }
 
 // ---------------------------------------------------------------------------

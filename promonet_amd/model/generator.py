@@ -73,8 +73,11 @@ class Generator(torch.nn.Module):
         speakers,
         spectral_balance_ratios,
         loudness_ratios,
-        previous_samples=None
+        previous_samples=None,
+        lengths=None
     ):
+        """`lengths` (B,) frames (not in the reference): ragged batch of
+        zero-padded utterances, each synthesised exactly as if alone."""
         features_cl = self._features(
             loudness, pitch, periodicity, ppg, channels_last=True)
         global_features = self.prepare_global_features(
@@ -82,9 +85,12 @@ class Generator(torch.nn.Module):
         if self.fargan:
             if previous_samples is None:
                 previous_samples = self.default_previous_samples
+            if lengths is not None:
+                raise NotImplementedError('ragged FARGAN batches')
             return self.model.forward_channels_last(
                 features_cl, global_features, previous_samples)
-        return self.model.forward_channels_last(features_cl, global_features)
+        return self.model.forward_channels_last(
+            features_cl, global_features, lengths)
 
     def prepare_features(self, loudness, pitch, periodicity, ppg):
         """(B, 113, T) conditioning tensor (generator.py:137-197)."""

@@ -178,11 +178,13 @@ class HiFiGAN(torch.nn.Module):
         (promonet/model/hifigan.py:63)."""
         return self._run(x, g, channels_last=False)
 
-    def forward_channels_last(self, x_cl, g):
-        """x_cl (B, T, C_pad) as written by `pm_prepare_features`."""
-        return self._run(x_cl, g, channels_last=True)
+    def forward_channels_last(self, x_cl, g, lengths=None):
+        """x_cl (B, T, C_pad) as written by `pm_prepare_features`; `lengths`
+        (B,) frames makes the batch ragged: every utterance is synthesised
+        as if alone, the audio past its end is zero."""
+        return self._run(x_cl, g, channels_last=True, lengths=lengths)
 
-    def _run(self, x, g, channels_last):
+    def _run(self, x, g, channels_last, lengths=None):
         _lib.require_gpu(x)
         engine = self.engine()
         lib = _lib.lib()
@@ -203,8 +205,20 @@ class HiFiGAN(torch.nn.Module):
         out = torch.empty(
             batch, 1, frames * self.hopsize, dtype=torch.float32,
             device=x.device)
+        if lengths is not None:
+            lengths = torch.as_tensor(lengths).to(
+                device=x.device, dtype=torch.int32).contiguous()
+            if lengths.shape != (batch,):
+                raise ValueError('lengths must have shape (B,)')
         with torch.cuda.device(x.device):
             workspace = self.workspace(batch, frames, x.device)
+            if lengths is not None:
+                _lib.check(lib.pm_hifigan_forward_ragged(
+                    engine, _lib.ptr(x), int(channels_last), _lib.ptr(g),
+                    g.shape[0], _lib.ptr(lengths, torch.int32), _lib.ptr(out),
+                    batch, frames, workspace.data_ptr(), workspace.numel(),
+                    _lib.stream()))
+                return out
             fn = lib.pm_hifigan_forward_cl if channels_last \
                 else lib.pm_hifigan_forward
             _lib.check(fn(

@@ -102,11 +102,14 @@ def from_features_batched(
     spectral_balance_ratios: Union[float, torch.Tensor] = 1.,
     loudness_ratios: Union[float, torch.Tensor] = 1.,
     checkpoint: Optional[Union[str, os.PathLike]] = None,
-    gpu: Optional[int] = None
+    gpu: Optional[int] = None,
+    lengths: Optional[Union[torch.Tensor, List[int]]] = None
 ) -> torch.Tensor:
     """Batched synthesis: (B, 8|513, T), (B, T), (B, T), (B, 40, T) ->
     (B, 1, 256 T). Per-utterance speakers and ratios; not in the reference,
-    whose public API returns utterance 0 only."""
+    whose public API returns utterance 0 only. `lengths` (B,) frames: the
+    utterances are zero-padded to T and each is synthesised exactly as if
+    alone (audio past 256 * lengths[b] is zero)."""
     device = _device(gpu, pitch)
     batch = pitch.shape[0]
 
@@ -125,7 +128,7 @@ def from_features_batched(
             ppg.to(device), per_item(speakers, torch.long),
             per_item(spectral_balance_ratios, torch.float),
             per_item(loudness_ratios, torch.float),
-            model.default_previous_samples)
+            model.default_previous_samples, lengths)
 
 
 def from_file(
@@ -218,6 +221,60 @@ def from_files_to_files(
             loudness_ratio=loudness_ratio,
             checkpoint=checkpoint,
             gpu=gpu)
+
+
+def from_files_to_files_batched(
+    loudness_files: List[Union[str, os.PathLike]],
+    pitch_files: List[Union[str, os.PathLike]],
+    periodicity_files: List[Union[str, os.PathLike]],
+    ppg_files: List[Union[str, os.PathLike]],
+    output_files: List[Union[str, os.PathLike]],
+    speakers: Optional[List[int]] = None,
+    spectral_balance_ratio: float = 1.,
+    loudness_ratio: float = 1.,
+    checkpoint: Optional[Union[str, os.PathLike]] = None,
+    gpu: Optional[int] = None,
+    batch_size: int = 32
+) -> None:
+    """`from_files_to_files` with the files synthesised `batch_size` at a
+    time (sorted by length, zero-padded, ragged-exact) instead of the
+    reference's one-utterance loop (synthesize/core.py:158-201). Same files,
+    same audio as the sequential path. SURVEY.md 8(f) item 2."""
+    device = _device(gpu)
+    if speakers is None:
+        speakers = [0] * len(pitch_files)
+    items = []
+    for index in range(len(pitch_files)):
+        pitch = torch.load(pitch_files[index])
+        items.append((
+            pitch.shape[-1], index, torch.load(loudness_files[index]), pitch,
+            torch.load(periodicity_files[index]),
+            promonet_amd.load.ppg(ppg_files[index], pitch.shape[-1])))
+    items.sort(key=lambda item: item[0])
+    for start in range(0, len(items), batch_size):
+        group = items[start:start + batch_size]
+        frames = max(item[0] for item in group)
+
+        def padded(tensors):
+            out = torch.zeros(
+                (len(tensors),) + tuple(tensors[0].shape[:-1]) + (frames,))
+            for row, tensor in zip(out, tensors):
+                row[..., :tensor.shape[-1]] = tensor
+            return out.to(device)
+
+        audio = from_features_batched(
+            padded([item[2].reshape(-1, item[0]) for item in group]),
+            padded([item[3].reshape(item[0]) for item in group]),
+            padded([item[4].reshape(item[0]) for item in group]),
+            padded([item[5].reshape(-1, item[0]) for item in group]),
+            [speakers[item[1]] for item in group], spectral_balance_ratio,
+            loudness_ratio, checkpoint, gpu,
+            lengths=[item[0] for item in group]).cpu()
+        for row, item in zip(audio, group):
+            output_file = Path(output_files[item[1]])
+            output_file.parent.mkdir(exist_ok=True, parents=True)
+            save_audio(
+                output_file, row[:, :item[0] * promonet_amd.HOPSIZE])
 
 
 ###############################################################################
