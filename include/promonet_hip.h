@@ -235,6 +235,15 @@ int pm_fargan_forward(pm_fargan_t h, const float* features, int features_cl,
                       float* out, int batch, int frames, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Kernel selection: 0 auto (clusters of 8 workgroups per utterance up to 160
+ * utterances per launch, else one persistent workgroup per utterance),
+ * 1 force the latter, 2 force clusters.                                     */
+int pm_fargan_set_mode(pm_fargan_t h, int mode);
+/* Debug / safety: synchronise and report whether an inter-workgroup exchange
+ * of the last forward on `workspace` timed out (never expected).            */
+int pm_fargan_check(pm_fargan_t h, int batch, int frames, void* workspace,
+                    void* stream);
+
 /* ---- preprocessing: promonet/preprocess/spectrogram.py, loudness.py ---- */
 /* spectrogram.from_audio (spectrogram.py:15-60): reflect-pad 384, hann-1024
  * hop-256 framed DFT, sqrt(re^2 + im^2 + 1e-6): audio (B, N) ->

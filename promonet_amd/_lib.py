@@ -72,6 +72,8 @@ SIGNATURES = {
     'pm_fargan_finalize': (_I, [_P, _P]),
     'pm_fargan_workspace_bytes': (_S, [_P, _I, _I]),
     'pm_fargan_forward': (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _S, _P]),
+    'pm_fargan_set_mode': (_I, [_P, _I]),
+    'pm_fargan_check': (_I, [_P, _I, _I, _P, _P]),
     'pm_stft_scratch_bytes': (_S, [_I, _I]),
     'pm_stft_magnitude': (_I, [_P, _P, _I, _I, _P, _S, _P]),
     'pm_linear_to_mel': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -1153,6 +1153,7 @@ struct FLayer {
 
 struct pm_fargan_s {
     int nfeat, G, dtype;
+    int mode = 0;        // 0 auto, 1 one workgroup per utterance, 2 clusters
     std::vector<FLayer> layers;
     bool finalized = false;
 };
@@ -1211,6 +1212,7 @@ extern "C" int pm_fargan_destroy(pm_fargan_t h) {
 }
 
 static int fargan_pack(pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) {
+    const int gru = l.rows == 768 ? 1 : 0;   // gate-interleaved GRU rows
     const size_t elems = (size_t)l.rpad * l.kpad;
     if (!l.packed)
         HIP_TRY(hipMalloc(&l.packed, elems * (h->dtype == PM_F32 ? 4 : 2)));
@@ -1218,11 +1220,11 @@ static int fargan_pack(pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) 
     if (h->dtype == PM_F32)
         hipLaunchKernelGGL(pm_fargan_pack_kernel<float>, dim3(grid), dim3(256),
                            0, s, w, (float*)l.packed, l.rows, l.cols, l.rpad,
-                           l.kpad);
+                           l.kpad, gru);
     else
         hipLaunchKernelGGL(pm_fargan_pack_kernel<_Float16>, dim3(grid),
                            dim3(256), 0, s, w, (_Float16*)l.packed, l.rows,
-                           l.cols, l.rpad, l.kpad);
+                           l.cols, l.rpad, l.kpad, gru);
     HIP_TRY(hipGetLastError());
     l.has = true;
     return PM_OK;
@@ -1291,14 +1293,43 @@ extern "C" int pm_fargan_finalize(pm_fargan_t h, void* stream) {
     return PM_OK;
 }
 
+// Kernel choice. Measured (MI355X, 10 s utterances): clusters of 8 workgroups
+// take 140 ms per wave of 32 utterances, one workgroup per utterance takes
+// 720 ms per wave of 256 -> clusters win up to ~160 utterances per launch.
+// PM_FARGAN=single|cluster overrides, as does pm_fargan_set_mode().
+static bool fargan_use_cluster(pm_fargan_t h, int B) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("PM_FARGAN");
+        forced = !e ? 0 : (!strcmp(e, "single") ? 1 : (!strcmp(e, "cluster") ? 2 : 0));
+    }
+    const int mode = h->mode ? h->mode : forced;
+    if (mode == 1) return false;
+    if (mode == 2) return true;
+    return B <= 160;
+}
+
+extern "C" int pm_fargan_set_mode(pm_fargan_t h, int mode) {
+    if (!h || mode < 0 || mode > 2) return fail(PM_EINVAL, "bad mode");
+    h->mode = mode;
+    return PM_OK;
+}
+
+static const int FG_MAX_CLUSTERS = 32;   // 32 x 8 workgroups = one per CU
+
+static size_t fargan_state_bytes() {
+    return align256((size_t)FG_MAX_CLUSTERS * FG_CSTATE * 4 + 256);
+}
+
 extern "C" size_t pm_fargan_workspace_bytes(pm_fargan_t h, int B, int T) {
     if (!h || B < 1 || T < 1) return 0;
-    return align256((size_t)B * T * pad32(h->nfeat + 1) * sizeof(float));
+    return align256((size_t)B * T * pad32(h->nfeat + 1) * sizeof(float)) +
+           fargan_state_bytes();
 }
 
 template <class WT>
 static int fargan_launch(
-    pm_fargan_t h, const FarganArgs& a, hipStream_t s) {
+    pm_fargan_t h, const FarganArgs& a, hipStream_t s, void* cluster_state) {
     FarganWeights<WT> w;
     auto P = [&](int i) { return (const WT*)h->layers[i].packed; };
     w.cond[0] = P(0); w.cond[1] = P(1); w.cond[2] = P(2);
@@ -1307,9 +1338,39 @@ static int fargan_launch(
         w.gru_ih[n] = P(5 + n); w.gru_hh[n] = P(8 + n); w.gru_glu[n] = P(11 + n);
     }
     w.skip = P(14); w.skip_glu = P(15); w.out = P(16);
+    if (cluster_state) {
+        // counters / payload / error word are re-initialised on every call
+        HIP_TRY(hipMemsetAsync(cluster_state, 0, fargan_state_bytes(), s));
+        FarganClusterArgs ca;
+        ca.f = a;
+        ca.state = (unsigned*)cluster_state;
+        ca.error = ca.state + (size_t)FG_MAX_CLUSTERS * FG_CSTATE;
+        ca.nclusters = a.B < FG_MAX_CLUSTERS ? a.B : FG_MAX_CLUSTERS;
+        hipLaunchKernelGGL(pm_fargan_cluster_kernel<WT>,
+                           dim3(ca.nclusters * FG_G), dim3(FG_THREADS), 0, s,
+                           ca, w);
+        HIP_TRY(hipGetLastError());
+        return PM_OK;
+    }
     hipLaunchKernelGGL(pm_fargan_kernel<WT>, dim3(a.B), dim3(FG_THREADS), 0, s,
                        a, w);
     HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+// Synchronises `stream` and reports whether a cluster exchange of the last
+// forward on `workspace` gave up (bounded spin): PM_OK or PM_EHIP.
+extern "C" int pm_fargan_check(
+    pm_fargan_t h, int B, int T, void* ws, void* stream) {
+    if (!h || !ws) return fail(PM_EINVAL, "null argument");
+    if (!fargan_use_cluster(h, B)) return PM_OK;
+    unsigned flag = 0;
+    const char* state = (const char*)ws +
+        align256((size_t)B * T * pad32(h->nfeat + 1) * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(&flag, state + (size_t)FG_MAX_CLUSTERS * FG_CSTATE * 4,
+                           4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (flag) return fail(PM_EHIP, "FARGAN cluster exchange timed out");
     return PM_OK;
 }
 
@@ -1328,9 +1389,12 @@ extern "C" int pm_fargan_forward(
     hipStream_t s = (hipStream_t)stream;
     const int cpad = pad32(h->nfeat + 1);
     const float* fcl = features;
+    if (!ws || ws_bytes < pm_fargan_workspace_bytes(h, B, T))
+        return fail(PM_ENOMEM, "workspace too small");
+    void* cluster_state = fargan_use_cluster(h, B)
+        ? (char*)ws + align256((size_t)B * T * pad32(h->nfeat + 1) * sizeof(float))
+        : nullptr;
     if (!features_cl) {
-        if (!ws || ws_bytes < pm_fargan_workspace_bytes(h, B, T))
-            return fail(PM_ENOMEM, "workspace too small");
         dim3 grid((T + 31) / 32, cpad / 32, B);
         hipLaunchKernelGGL(pm_to_channels_last_kernel, grid, dim3(256), 0, s,
                            features, (float*)ws, h->nfeat + 1, T, cpad);
@@ -1341,6 +1405,6 @@ extern "C" int pm_fargan_forward(
     a.features_cl = fcl; a.global = g; a.previous = previous; a.out = out;
     a.B = B; a.T = T; a.cstride = cpad; a.nfeat = h->nfeat; a.G = h->G;
     a.global_batch = gbatch; a.previous_batch = pbatch;
-    return h->dtype == PM_F32 ? fargan_launch<float>(h, a, s)
-                              : fargan_launch<_Float16>(h, a, s);
+    return h->dtype == PM_F32 ? fargan_launch<float>(h, a, s, cluster_state)
+                              : fargan_launch<_Float16>(h, a, s, cluster_state);
 }

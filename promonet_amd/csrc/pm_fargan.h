@@ -75,10 +75,17 @@ __device__ __forceinline__ float fg_gemv(
 }
 
 // torch-layout W (rows, cols) fp32 -> [kpad / VEC][rpad][VEC], zero padded
+// GRU matrices (768 = 3 gates x 256 units) are stored gate-interleaved in
+// blocks of 32 units: packed row r = (j / 32) * 96 + gate * 32 + j % 32, so
+// that the 96 rows a cluster member needs for its 32 units are contiguous.
+__host__ __device__ __forceinline__ int fg_gru_row(int gate, int j) {
+    return (j >> 5) * 96 + gate * 32 + (j & 31);
+}
+
 template <class WT>
 __global__ __launch_bounds__(256) void pm_fargan_pack_kernel(
     const float* __restrict__ w, WT* __restrict__ out, int rows, int cols,
-    int rpad, int kpad) {
+    int rpad, int kpad, int gru) {
     constexpr int VEC = FgVec<WT>::VEC;
     const long long total = (long long)rpad * kpad;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -87,7 +94,9 @@ __global__ __launch_bounds__(256) void pm_fargan_pack_kernel(
     const int row = (i / VEC) % rpad;
     const int blk = i / ((long long)VEC * rpad);
     const int col = blk * VEC + e;
-    out[i] = (WT)((row < rows && col < cols) ? w[(size_t)row * cols + col]
+    int src = row;
+    if (gru) src = ((row % 96) / 32) * 256 + (row / 96) * 32 + (row % 32);
+    out[i] = (WT)((src < rows && col < cols) ? w[(size_t)src * cols + col]
                                              : 0.f);
 }
 
@@ -223,9 +232,11 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
                     w.gru_hh[n], hid[n], hid[n], 256, 256, tid);
                 __syncthreads();
                 if (tid < 256) {
-                    const float r = fg_sigmoid(part[tid] + part2[tid]);
-                    const float z = fg_sigmoid(part[256 + tid] + part2[256 + tid]);
-                    const float nn = tanhf(part[512 + tid] + r * part2[512 + tid]);
+                    const int ir = fg_gru_row(0, tid), iz = fg_gru_row(1, tid);
+                    const int in_ = fg_gru_row(2, tid);
+                    const float r = fg_sigmoid(part[ir] + part2[ir]);
+                    const float z = fg_sigmoid(part[iz] + part2[iz]);
+                    const float nn = tanhf(part[in_] + r * part2[in_]);
                     hid[n][tid] = (1.f - z) * nn + z * hid[n][tid];
                 }
                 __syncthreads();
@@ -264,6 +275,249 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
             }
             base = (base + FG_SUB) & (FG_PREV - 1);
             __syncthreads();
+        }
+    }
+}
+
+
+// ===========================================================================
+// Cluster variant: FG_G = 8 workgroups cooperate on one utterance.
+//
+// One CU streams the 9.2 MB of weights at ~45 GB/s: 213 us per sub-frame step.
+// Here workgroup g of a cluster owns rows [g R / 8, (g + 1) R / 8) of every
+// layer, so each streams 1/8 of the weights; the dispatcher places block b on
+// XCD b % 8 and g = b % 8, so each XCD's 4 MB L2 keeps exactly its 1.15 MB
+// slice resident for ALL clusters. After every layer the 8 slices of the
+// output vector are exchanged through a per-cluster global buffer:
+//   publish: write-through (sc1 = relaxed agent-scope atomic) stores, every
+//            storing wave drains vmcnt, barrier, ONE lane adds to the arrival
+//            counter (guide G16 recipe R1 - no fences);
+//   consume: one lane polls the counter relaxed (+ s_sleep) until the epoch's
+//            8 arrivals are in, barrier, sc1 loads (bypass the stale L1).
+// Placement-independent (correct for any block -> XCD map), two payload
+// buffers alternate by epoch parity, counters are zeroed by a memset node
+// before every launch, every spin is bounded and trips a global error word.
+// All other state (GRU states, sample history) is replicated per workgroup.
+// ===========================================================================
+#define FG_G 8
+
+struct FgCluster {
+    unsigned* buf;        // [2][768] payload (float bits), this cluster
+    unsigned* counter;    // arrivals, monotonically increasing
+    unsigned* error;      // global: set when a bounded spin gave up
+    unsigned epoch;
+};
+
+#define FG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// `mine` (valid for tid < nmine) = element r0 + tid of a `total`-long vector;
+// on return dst[0..total) holds the whole vector in every member's LDS.
+__device__ __forceinline__ void fg_exchange(
+    FgCluster& c, float mine, int r0, int nmine, float* dst, int total,
+    int tid) {
+    unsigned* buf = c.buf + (c.epoch & 1u) * 768u;
+    if (tid < nmine)
+        __hip_atomic_store(buf + r0 + tid, __float_as_uint(mine), FG_RLX);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(c.counter, 1u, FG_RLX);
+        const unsigned target = FG_G * (c.epoch + 1u);
+        unsigned spins = 0;
+        while (__hip_atomic_load(c.counter, FG_RLX) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u &&
+                (spins > (1u << 24) || __hip_atomic_load(c.error, FG_RLX))) {
+                __hip_atomic_store(c.error, 1u, FG_RLX);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < total)
+        dst[tid] = __uint_as_float(__hip_atomic_load(buf + tid, FG_RLX));
+    __syncthreads();
+    c.epoch += 1u;
+}
+
+// This member's RW rows (r0 .. r0 + RW) of y = W x: every thread takes one
+// (row, K-slice) pair, partial sums meet in LDS. Returns the row's sum in
+// threads tid < RW.
+template <class WT, int RW, int RPAD>
+__device__ __forceinline__ float fg_slice(
+    const WT* __restrict__ w, const float* xa, const float* xb, int split,
+    int kpad, int r0, float* part, int tid) {
+    constexpr int VEC = FgVec<WT>::VEC;
+    constexpr int PARTS = FG_THREADS / RW;
+    const int row = tid % RW, p = tid / RW;
+    float acc0 = 0.f, acc1 = 0.f;
+    if (p < PARTS) {
+        const int blocks = kpad / VEC;
+        const int b0 = p * blocks / PARTS, b1 = (p + 1) * blocks / PARTS;
+        const int sb = split / VEC;
+        const WT* wp = w + ((size_t)b0 * RPAD + r0 + row) * VEC;
+#pragma unroll 4
+        for (int b = b0; b < b1; ++b) {
+            const float* x = b < sb ? xa + b * VEC : xb + (b - sb) * VEC;
+            const float d = FgVec<WT>::dot(wp, x);
+            if (b & 1) acc1 += d; else acc0 += d;
+            wp += (size_t)RPAD * VEC;
+        }
+    }
+    part[tid] = acc0 + acc1;
+    __syncthreads();
+    float sum = 0.f;
+    if (tid < RW) {
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) sum += part[tid + q * RW];
+    }
+    __syncthreads();
+    return sum;
+}
+
+struct FarganClusterArgs {
+    FarganArgs f;
+    unsigned* state;      // per cluster: [2 * 768 payload | counter | pad]
+    unsigned* error;
+    int nclusters;
+};
+
+#define FG_CSTATE (2 * 768 + 16)   // uint32 words of cluster state
+
+template <class WT>
+__global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
+    FarganClusterArgs ca, FarganWeights<WT> w) {
+    const FarganArgs& a = ca.f;
+    constexpr int NT = FG_THREADS;
+    constexpr int CPAD = 376;
+    __shared__ __attribute__((aligned(16))) float condin[CPAD];
+    __shared__ __attribute__((aligned(16))) float c1[384];
+    __shared__ __attribute__((aligned(16))) float c2[384];
+    __shared__ __attribute__((aligned(16))) float cond[512];
+    __shared__ __attribute__((aligned(16))) float subin[2 * FG_SUBIN + 8];
+    __shared__ __attribute__((aligned(16))) float skipbuf[FG_SKIP];
+    __shared__ __attribute__((aligned(16))) float hid[3][FG_HOP];
+    __shared__ __attribute__((aligned(16))) float f1[FG_HOP];
+    __shared__ __attribute__((aligned(16))) float part[NT];
+    __shared__ __attribute__((aligned(16))) float part2[NT];
+    __shared__ float prev[FG_PREV];
+    __shared__ float fresh[FG_SUB];
+
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x % FG_G;          // = XCD under the b % 8 dispatch
+    const int cluster = blockIdx.x / FG_G;
+    const int T = a.T;
+    const int nin = a.nfeat + a.G;
+    FgCluster c;
+    c.buf = ca.state + (size_t)cluster * FG_CSTATE;
+    c.counter = c.buf + 2 * 768;
+    c.error = ca.error;
+    c.epoch = 0;
+
+#pragma unroll 1
+    for (int u = cluster; u < a.B; u += ca.nclusters) {
+        const float* feat = a.features_cl + (size_t)u * T * a.cstride;
+        const float* glob =
+            a.global + (size_t)(a.global_batch == 1 ? 0 : u) * a.G;
+        float* out = a.out + (size_t)u * T * FG_HOP;
+
+        for (int i = tid; i < 3 * FG_HOP; i += NT) (&hid[0][0])[i] = 0.f;
+        for (int i = tid; i < 2 * FG_SUBIN + 8; i += NT) subin[i] = 0.f;
+        for (int i = tid; i < CPAD; i += NT) condin[i] = 0.f;
+        for (int i = tid; i < FG_PREV; i += NT)
+            prev[i] = a.previous
+                ? a.previous[(size_t)(a.previous_batch == 1 ? 0 : u) * FG_PREV + i]
+                : 0.f;
+        int base = 0;
+        __syncthreads();
+
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            const float* row = feat + (size_t)t * a.cstride;
+            if (tid < a.nfeat) condin[tid] = row[tid];
+            else if (tid < nin) condin[tid] = glob[tid - a.nfeat];
+            const int period = (int)rintf(row[a.nfeat]);
+            __syncthreads();
+            // conditioning network: 384 / 384 / 512 rows -> 48 / 48 / 64 each
+            float v = fg_slice<WT, 48, 384>(w.cond[0], condin, condin, CPAD, CPAD, g * 48, part, tid);
+            fg_exchange(c, tanhf(v), g * 48, 48, c1, 384, tid);
+            v = fg_slice<WT, 48, 384>(w.cond[1], c1, c1, CPAD, CPAD, g * 48, part, tid);
+            fg_exchange(c, tanhf(v), g * 48, 48, c2, 384, tid);
+            v = fg_slice<WT, 64, 512>(w.cond[2], c2, c2, CPAD, CPAD, g * 64, part, tid);
+            fg_exchange(c, tanhf(v), g * 64, 64, cond, 512, tid);
+
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {
+                if (tid < 128) {
+                    subin[tid] = cond[4 * tid + s];
+                } else if (tid < 192) {
+                    const int i = tid - 128;
+                    const float x = prev[(base + FG_PREV - FG_SUB + i) & (FG_PREV - 1)];
+                    subin[128 + i] = x;
+                    skipbuf[1088 + i] = x;
+                } else if (tid < 260) {
+                    const int i = tid - 192;
+                    int idx = FG_PREV - period + i - 2;
+                    if (idx >= FG_PREV) idx -= period;
+                    idx = idx < 0 ? 0 : (idx >= FG_PREV ? FG_PREV - 1 : idx);
+                    const float x = prev[(base + idx) & (FG_PREV - 1)];
+                    subin[192 + i] = x;
+                    if (i >= 2 && i < 66) skipbuf[1024 + i - 2] = x;
+                }
+                __syncthreads();
+
+                // framewise conv + GLU
+                v = fg_slice<WT, 32, 256>(w.fwconv, subin, subin, 520, 520, g * 32, part, tid);
+                fg_exchange(c, tanhf(v), g * 32, 32, f1, 256, tid);
+                v = fg_slice<WT, 32, 256>(w.fwconv_glu, f1, f1, 256, 256, g * 32, part, tid);
+                fg_exchange(c, tid < 32 ? f1[g * 32 + tid] * fg_sigmoid(v) : 0.f,
+                            g * 32, 32, skipbuf + 768, 256, tid);
+
+#pragma unroll 1
+                for (int n = 0; n < 3; ++n) {
+                    const float* xa = n == 0 ? skipbuf + 768 : skipbuf + (n - 1) * 256;
+                    // this member's 32 units x 3 gates = packed rows g*96 ..
+                    const float gi = fg_slice<WT, 96, 768>(
+                        w.gru_ih[n], xa, skipbuf + 1024, 256, 384, g * 96, part, tid);
+                    if (tid < 96) part2[tid] = gi;
+                    const float gh = fg_slice<WT, 96, 768>(
+                        w.gru_hh[n], hid[n], hid[n], 256, 256, g * 96, part, tid);
+                    if (tid < 96) part2[96 + tid] = gh;
+                    __syncthreads();
+                    float hnew = 0.f;
+                    if (tid < 32) {
+                        const float r = fg_sigmoid(part2[tid] + part2[96 + tid]);
+                        const float z = fg_sigmoid(part2[32 + tid] + part2[128 + tid]);
+                        const float nn = tanhf(part2[64 + tid] + r * part2[160 + tid]);
+                        hnew = (1.f - z) * nn + z * hid[n][g * 32 + tid];
+                    }
+                    __syncthreads();
+                    fg_exchange(c, hnew, g * 32, 32, hid[n], 256, tid);
+                    v = fg_slice<WT, 32, 256>(w.gru_glu[n], hid[n], hid[n], 256, 256, g * 32, part, tid);
+                    fg_exchange(c, tid < 32 ? hid[n][g * 32 + tid] * fg_sigmoid(v) : 0.f,
+                                g * 32, 32, skipbuf + n * 256, 256, tid);
+                }
+
+                v = fg_slice<WT, 32, 256>(w.skip, skipbuf, skipbuf, FG_SKIP, FG_SKIP, g * 32, part, tid);
+                fg_exchange(c, tanhf(v), g * 32, 32, f1, 256, tid);
+                v = fg_slice<WT, 32, 256>(w.skip_glu, f1, f1, 256, 256, g * 32, part, tid);
+                // f1 is both the GLU input and the exchange target: stage
+                // the gated values through part2 first
+                if (tid < 32) part2[tid] = f1[g * 32 + tid] * fg_sigmoid(v);
+                __syncthreads();
+                fg_exchange(c, tid < 32 ? part2[tid] : 0.f, g * 32, 32, f1, 256, tid);
+                v = fg_slice<WT, 8, 64>(w.out, f1, f1, 256, 256, g * 8, part, tid);
+                const float sample = tanhf(v);
+                if (tid < 8) out[(size_t)t * FG_HOP + s * FG_SUB + g * 8 + tid] = sample;
+                fg_exchange(c, sample, g * 8, 8, fresh, FG_SUB, tid);
+                if (tid < FG_SUB) {
+                    prev[(base + tid) & (FG_PREV - 1)] = fresh[tid];
+                } else if (tid >= 256 && tid < 256 + FG_SUBIN) {
+                    subin[FG_SUBIN + tid - 256] = subin[tid - 256];
+                }
+                base = (base + FG_SUB) & (FG_PREV - 1);
+                __syncthreads();
+            }
         }
     }
 }

@@ -26,6 +26,8 @@ class FARGAN(torch.nn.Module):
         self.global_channels = global_channels
         self.hopsize = promonet_amd.HOPSIZE
         self.weight_dtype = promonet_amd.FARGAN_WEIGHT_DTYPE
+        self.check_exchange = True
+        self.kernel_mode = 0    # 0 auto, 1 workgroup per utterance, 2 clusters
         for key, tensor in self._initial_state().items():
             attach(self, key, tensor)
         self._engine = None
@@ -165,6 +167,7 @@ class FARGAN(torch.nn.Module):
         out = torch.empty(
             batch, 1, frames * self.hopsize, dtype=torch.float32,
             device=x.device)
+        _lib.check(lib.pm_fargan_set_mode(engine, self.kernel_mode))
         with torch.cuda.device(x.device):
             size = lib.pm_fargan_workspace_bytes(engine, batch, frames)
             if self._workspace is None or self._workspace.numel() < size or \
@@ -176,6 +179,12 @@ class FARGAN(torch.nn.Module):
                 g.shape[0], pointer, pbatch, _lib.ptr(out), batch, frames,
                 self._workspace.data_ptr(), self._workspace.numel(),
                 _lib.stream()))
+            if self.check_exchange:
+                # the cluster kernel's inter-workgroup waits are bounded; a
+                # tripped bound must not pass as audio (costs one stream sync)
+                _lib.check(lib.pm_fargan_check(
+                    engine, batch, frames, self._workspace.data_ptr(),
+                    _lib.stream()))
         return out
 
     def remove_weight_norm(self):

@@ -20,7 +20,7 @@ for dtype in ('fp32', 'f16'):
     promonet_amd.configure(MODEL='fargan', FARGAN_WEIGHT_DTYPE=dtype)
     torch.manual_seed(0)
     model = promonet_amd.model.Generator().to(device).eval()
-    for batch in (32, 256):
+    for batch in (1, 32, 256):
         inputs = synthetic_inputs(batch, frames, 1234, device)
         with torch.inference_mode():
             model(*inputs, None)

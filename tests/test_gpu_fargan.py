@@ -38,9 +38,15 @@ def on(device, inputs):
     return [t.to(device) for t in inputs]
 
 
+@pytest.mark.parametrize('mode', [1, 2])
 @pytest.mark.parametrize('dtype', ['fp32', 'f16'])
-def test_matches_reference_golden(device, golden_fargan, fargan_model, dtype):
+def test_matches_reference_golden(
+    device, golden_fargan, fargan_model, dtype, mode
+):
+    """mode 1: one persistent workgroup per utterance; mode 2: clusters of 8
+    workgroups exchanging layer outputs through global memory."""
     model = fargan_model(dtype)
+    model.model.kernel_mode = mode
     for name in ('b2_t8', 'b1_t60', 'b3_t25'):
         entry = golden_fargan[name]
         inputs = oracle.synthetic_inputs(
@@ -55,6 +61,24 @@ def test_matches_reference_golden(device, golden_fargan, fargan_model, dtype):
         print(f'fargan {dtype} {name}: max-abs {error:.3e} '
               f'(abs-max {entry["audio"].abs().max().item():.3f})')
         assert error < GATE[dtype], name
+    model.model.kernel_mode = 0
+
+
+def test_cluster_waves_and_determinism(device, fargan_model):
+    """More utterances than clusters (each cluster walks several utterances,
+    its arrival counter keeps counting), repeated runs bit-identical, and the
+    two kernels agree."""
+    model = fargan_model('fp32')
+    inputs = on(device, oracle.synthetic_inputs(37, 6, seed=15))
+    with torch.inference_mode():
+        model.model.kernel_mode = 2
+        clustered = model(*inputs, None)
+        again = model(*inputs, None)
+        model.model.kernel_mode = 1
+        single = model(*inputs, None)
+    model.model.kernel_mode = 0
+    assert torch.equal(clustered, again)
+    assert max_abs(clustered, single) < 2e-6
 
 
 def test_long_sequence_vs_oracle(device, fargan_model):
