@@ -18,6 +18,7 @@ def patch(promonet):
                 promonet_amd.configure(**{name: value})
 
     promonet.model.HiFiGAN = promonet_amd.model.HiFiGAN
+    promonet.model.FARGAN = promonet_amd.model.FARGAN
     promonet.model.Generator = promonet_amd.model.Generator
     for name in (
         'from_features', 'from_file', 'from_file_to_file',
