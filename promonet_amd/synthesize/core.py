@@ -61,22 +61,14 @@ def from_features(
     checkpoint: Optional[Union[str, os.PathLike]] = None,
     gpu: Optional[int] = None
 ) -> torch.Tensor:
-    """Perform speech synthesis (synthesize/core.py:18-59)
+    """Synthesize one utterance from its features (synthesize/core.py:18-59).
 
-    Args:
-        loudness: The loudness contour
-        pitch: The pitch contour
-        periodicity: The periodicity contour
-        ppg: The phonetic posteriorgram
-        speaker: The speaker index
-        spectral_balance_ratio: > 1 for Alvin and the Chipmunks; < 1 for Patrick Star
-        loudness_ratio: > 1 for louder; < 1 for quieter
-        checkpoint: The generator checkpoint
-        gpu: The GPU index (required: there is no CPU path)
-
-    Returns
-        generated: The generated speech, (1, samples) float32 - item 0 of the
-            batch only, as in the reference (core.py:281)
+    loudness (8|513, T) or (B, ., T) dB, pitch (B, T) Hz, periodicity (B, T),
+    ppg (B, 40, T); `speaker` index, the two augmentation ratios (> 1 raises
+    the spectral balance / the loudness), optional generator checkpoint file
+    or directory, and the GPU index (required: there is no CPU path).
+    Returns (1, 256 T) float32 - utterance 0 of the batch only, as the
+    reference does (core.py:281).
     """
     device = _device(gpu, pitch)
     if loudness.ndim == 2:
@@ -131,6 +123,16 @@ def from_features_batched(
             model.default_previous_samples, lengths)
 
 
+def _load_features(loudness_file, pitch_file, periodicity_file, ppg_file):
+    """torch.load the four feature files of one utterance; the PPG is
+    resampled to the pitch's frame count and gets its batch axis."""
+    pitch = torch.load(pitch_file)
+    ppg = promonet_amd.load.ppg(ppg_file, resample_length=pitch.shape[-1])
+    return (
+        torch.load(loudness_file), pitch, torch.load(periodicity_file),
+        ppg[None])
+
+
 def from_file(
     loudness_file: Union[str, os.PathLike],
     pitch_file: Union[str, os.PathLike],
@@ -142,23 +144,15 @@ def from_file(
     checkpoint: Optional[Union[str, os.PathLike]] = None,
     gpu: Optional[int] = None
 ) -> torch.Tensor:
-    """Perform speech synthesis from features on disk (core.py:62-111)"""
+    """`from_features` on features stored as .pt files (core.py:62-111);
+    returns (1, samples) float32 on the GPU."""
     device = _device(gpu)
-    loudness = torch.load(loudness_file)
-    pitch = torch.load(pitch_file)
-    periodicity = torch.load(periodicity_file)
-    ppg = promonet_amd.load.ppg(
-        ppg_file, resample_length=pitch.shape[-1])[None]
+    features = [
+        tensor.to(device) for tensor in _load_features(
+            loudness_file, pitch_file, periodicity_file, ppg_file)]
     return from_features(
-        loudness.to(device),
-        pitch.to(device),
-        periodicity.to(device),
-        ppg.to(device),
-        speaker,
-        spectral_balance_ratio,
-        loudness_ratio,
-        checkpoint,
-        gpu)
+        *features, speaker, spectral_balance_ratio, loudness_ratio,
+        checkpoint, gpu)
 
 
 def from_file_to_file(
@@ -173,22 +167,13 @@ def from_file_to_file(
     checkpoint: Optional[Union[str, os.PathLike]] = None,
     gpu: Optional[int] = None
 ) -> None:
-    """Perform speech synthesis from features on disk and save
-    (core.py:114-155)"""
-    generated = from_file(
-        loudness_file,
-        pitch_file,
-        periodicity_file,
-        ppg_file,
-        speaker,
-        spectral_balance_ratio,
-        loudness_ratio,
-        checkpoint,
-        gpu
-    ).to('cpu')
-    output_file = Path(output_file)
-    output_file.parent.mkdir(exist_ok=True, parents=True)
-    save_audio(output_file, generated)
+    """`from_file`, then write a 22.05 kHz wav (core.py:114-155)."""
+    audio = from_file(
+        loudness_file, pitch_file, periodicity_file, ppg_file, speaker,
+        spectral_balance_ratio, loudness_ratio, checkpoint, gpu)
+    target = Path(output_file)
+    target.parent.mkdir(exist_ok=True, parents=True)
+    save_audio(target, audio.cpu())
 
 
 def from_files_to_files(
@@ -203,24 +188,17 @@ def from_files_to_files(
     checkpoint: Optional[Union[str, os.PathLike]] = None,
     gpu: Optional[int] = None
 ) -> None:
-    """Perform batched speech synthesis from features on disk and save
-    (core.py:158-201; a sequential loop, as in the reference)"""
-    if speakers is None:
-        speakers = [0] * len(pitch_files)
-    iterator = zip(
-        loudness_files,
-        pitch_files,
-        periodicity_files,
-        ppg_files,
-        output_files,
-        speakers)
-    for item in iterator:
+    """One `from_file_to_file` per utterance, in order - the reference's
+    sequential behaviour (core.py:158-201). `from_files_to_files_batched`
+    below is the throughput path."""
+    count = len(pitch_files)
+    speakers = [0] * count if speakers is None else speakers
+    for index in range(count):
         from_file_to_file(
-            *item,
-            spectral_balance_ratio=spectral_balance_ratio,
-            loudness_ratio=loudness_ratio,
-            checkpoint=checkpoint,
-            gpu=gpu)
+            loudness_files[index], pitch_files[index],
+            periodicity_files[index], ppg_files[index], output_files[index],
+            speakers[index], spectral_balance_ratio, loudness_ratio,
+            checkpoint, gpu)
 
 
 def from_files_to_files_batched(

@@ -207,3 +207,29 @@ def test_fargan_engine_validation():
                                     ctypes.byref(handle)) == -1
     assert library.pm_fargan_create(113, 258, _lib.PM_BF16,
                                     ctypes.byref(handle)) == -1
+
+
+def test_patch_swaps_into_the_real_reference():
+    """Only where /root/reference exists (the build container): the literal
+    drop-in of INTEGRATION.md section 1."""
+    import reference_import
+    if not reference_import.available():
+        pytest.skip('reference not present on this machine')
+    promonet = reference_import.load()
+    original = promonet.synthesize.from_features
+    promonet_amd.patch(promonet)
+    try:
+        assert promonet.model.Generator is promonet_amd.model.Generator
+        assert promonet.model.HiFiGAN is promonet_amd.model.HiFiGAN
+        assert promonet.synthesize.from_features is \
+            promonet_amd.synthesize.from_features
+        assert promonet.synthesize.core.generate is \
+            promonet_amd.synthesize.generate
+        assert promonet.preprocess.spectrogram.from_audio is \
+            promonet_amd.preprocess.spectrogram.from_audio
+        # same constructor contract: no arguments, reference state-dict keys
+        model = promonet.model.Generator()
+        assert len(model.state_dict()) == 238
+        assert promonet_amd.NUM_FEATURES == promonet.NUM_FEATURES
+    finally:
+        promonet.synthesize.from_features = original
