@@ -201,6 +201,19 @@ def run(which):
     assert (oracle.grid_sample(sequence, grid) -
             golden['edit']['sample']['linear']).abs().max() < 1e-6
 
+    # packed (nn~) interface: generator.py:255-422
+    packed_inputs = oracle.synthetic_inputs(2, 16, seed=17)
+    with torch.inference_mode():
+        packed = model.pack_features(
+            packed_inputs[0], packed_inputs[1][:, None],
+            packed_inputs[2][:, None], *packed_inputs[3:])
+        golden['packed'] = {
+            'frames': 16, 'input_seed': 17, 'packed': packed,
+            'audio': model.packed_inference(packed),
+            'labels': len(model.labels())}
+    assert packed.shape == (2, 53, 16)
+    assert golden['packed']['audio'].shape == (2, 1, 16 * 256)
+
     # import-time constants the host mirror must reproduce
     golden['constants'] = {
         key: getattr(promonet, key) for key in (

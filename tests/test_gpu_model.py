@@ -335,3 +335,29 @@ def test_files_to_files_batched(device, default_state, tmp_path):
         assert rate_a == rate_b == 22050
         assert audio_a.shape == audio_b.shape == (length * 256,)
         assert (audio_a == audio_b).all()
+
+
+def test_packed_interface(device, golden_default, default_state):
+    """pack_features / unpack_features / packed_inference (the nn~ buffer
+    contract, generator.py:255-422) against the real reference's output."""
+    model = make_model(default_state, 'fp32', device)
+    entry = golden_default['packed']
+    inputs = oracle.synthetic_inputs(2, entry['frames'], seed=entry['input_seed'])
+    with torch.inference_mode():
+        packed = model.pack_features(
+            inputs[0].to(device), inputs[1][:, None].to(device),
+            inputs[2][:, None].to(device), *on(device, inputs[3:]))
+        assert packed.shape == entry['packed'].shape == (2, 53, entry['frames'])
+        # band means of ~-100 dB values: one fp32 ulp is 7.6e-6
+        assert max_abs(packed, entry['packed']) < 2e-5
+        audio = model.packed_inference(entry['packed'].to(device))
+        unpacked = model.unpack_features(entry['packed'].to(device))
+    assert audio.dtype == torch.float32
+    assert audio.shape == entry['audio'].shape
+    assert max_abs(audio, entry['audio']) < GATE['fp32']
+    assert len(model.labels()) == entry['labels'] == 53
+    assert torch.equal(unpacked[4].cpu(), inputs[4])
+    # the export-time self test of the reference (generator.py:363-368)
+    with torch.inference_mode():
+        zeros = model.packed_inference(torch.zeros(1, 53, 32, device=device))
+    assert tuple(zeros.shape) == (1, 1, 8192) and torch.isfinite(zeros).all()
