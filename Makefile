@@ -1,7 +1,7 @@
 # Build libpromonet_hip.so (gfx950) and nothing else. `make -j4`.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
-CXXFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-value
+CXXFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-value -fno-honor-nans
 SRC = promonet_amd/csrc
 OBJ = build/obj
 LIB = promonet_amd/lib/libpromonet_hip.so

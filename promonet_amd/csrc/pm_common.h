@@ -18,8 +18,16 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// max(v, 0.1 v) == (v > 0 ? v : 0.1 v) for every finite v (and keeps -0):
+// one v_max instead of v_cmp + v_cndmask (the conv TUs are built with
+// -fno-honor-nans so that no canonicalising v_max v,v is added)
 __device__ __forceinline__ float pm_lrelu(float v) {
-    return v > 0.f ? v : v * PM_LRELU_SLOPE;
+    return __builtin_fmaxf(v, v * PM_LRELU_SLOPE);
+}
+__device__ __forceinline__ float4 pm_lrelu4(float4 v) {
+    v.x = pm_lrelu(v.x); v.y = pm_lrelu(v.y);
+    v.z = pm_lrelu(v.z); v.w = pm_lrelu(v.w);
+    return v;
 }
 
 // ---------------------------------------------------------------------------

@@ -182,6 +182,36 @@ __device__ __forceinline__ void mma_taps(
                 __builtin_amdgcn_s_memtime();                                \
     } while (0)
 
+// The conv bias rides in the accumulator: the first MFMA of a tile takes the
+// bias vector as its C operand (no zero fill, no add in the epilogue). In the
+// 32x32 C/D layout register 4 g + r of a lane is channel 8 g + 4 (lane>>5) + r.
+template <int MTW>
+__device__ __forceinline__ void load_bias_vec(
+    floatx16 (&bv)[MTW], const float* __restrict__ bias, const int co_first) {
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 v = *reinterpret_cast<const float4*>(
+                bias + co_first + mt * 32 + 8 * g4);
+            bv[mt][4 * g4 + 0] = v.x; bv[mt][4 * g4 + 1] = v.y;
+            bv[mt][4 * g4 + 2] = v.z; bv[mt][4 * g4 + 3] = v.w;
+        }
+}
+
+template <int MTW, int NTW>
+__device__ __forceinline__ void init_acc(
+    floatx16 (&acc)[MTW][NTW], const floatx16 (&bv)[MTW]) {
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = bv[mt];
+}
+
+__device__ __forceinline__ float4 acc_quad(const floatx16& v, const int g4) {
+    return make_float4(v[4 * g4], v[4 * g4 + 1], v[4 * g4 + 2], v[4 * g4 + 3]);
+}
+
 // ---------------------------------------------------------------------------
 // Fused Block iteration
 // ---------------------------------------------------------------------------
@@ -244,7 +274,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int ln = lane & 31, lh = lane >> 5;
 
@@ -268,12 +298,11 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
     const int t_first = t0 - H2 - hd;
 
     floatx16 acc[MTW][NTW];
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    floatx16 bv[MTW];
+    if (LW == 0 || wave < WM * WN) {
+        load_bias_vec<MTW>(bv, a.b1, wm * MTW * 32 + 4 * lh);
+        init_acc<MTW, NTW>(acc, bv);
+    }
 
     // ---------------- conv1: K-loop over staged channel chunks -------------
     const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1) +
@@ -360,32 +389,36 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
 
     PM_STAMP(a, 2);
     if (ALIAS) __syncthreads();     // every wave is done with the x chunks
-    // ---------------- epilogue 1: bias, lrelu, zero-pad mask -> LDS --------
+    // ---------------- epilogue 1: lrelu, zero-pad mask -> LDS --------------
+    // (bias already in the accumulator; the mask only on tiles that straddle
+    // an utterance edge - a wave-uniform branch)
+    load_bias_vec<MTW>(bv, a.b2, wm * MTW * 32 + 4 * lh);
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         const int co_base = (wm * MTW + mt) * 32 + 4 * lh;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const int n = (wn * NTW + nt) * 32 + ln;
-            const int t = t0 - H2 + n;
-            const bool inside = (t >= 0) && (t < L);
+            const int n_first = (wn * NTW + nt) * 32;
+            const int n = n_first + ln;
+            const int t_tile = t0 - H2 + n_first;
+            if (t_tile >= 0 && t_tile + 32 <= L) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int co = co_base + 8 * g4;
-                const float4 bias =
-                    *reinterpret_cast<const float4*>(a.b1 + co);
-                float4 v;
-                v.x = pm_lrelu(acc[mt][nt][4 * g4 + 0] + bias.x);
-                v.y = pm_lrelu(acc[mt][nt][4 * g4 + 1] + bias.y);
-                v.z = pm_lrelu(acc[mt][nt][4 * g4 + 2] + bias.z);
-                v.w = pm_lrelu(acc[mt][nt][4 * g4 + 3] + bias.w);
-                if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                ET::store4(inter + n * SI + co * ET::ESZ, v);
+                for (int g4 = 0; g4 < 4; ++g4)
+                    ET::store4(inter + n * SI + (co_base + 8 * g4) * ET::ESZ,
+                               pm_lrelu4(acc_quad(acc[mt][nt], g4)));
+            } else {
+                const int t = t_tile + ln;
+                const bool inside = (t >= 0) && (t < L);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mt][nt][4 * g4 + r] = 0.f;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float4 v = pm_lrelu4(acc_quad(acc[mt][nt], g4));
+                    if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ET::store4(inter + n * SI + (co_base + 8 * g4) * ET::ESZ, v);
+                }
             }
         }
     }
+    init_acc<MTW, NTW>(acc, bv);
     __syncthreads();
     PM_STAMP(a, 3);
 
@@ -415,11 +448,10 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
             const int n = (wn * NTW + nt) * 32 + ln;
             const int t = t0 + n;
             if (n < TL && t < L) {
-                float4 bias[4], res[4], old[4];
+                float4 res[4], old[4];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int co = co_base + 8 * g4;
-                    bias[g4] = *reinterpret_cast<const float4*>(a.b2 + co);
                     res[g4] = *reinterpret_cast<const float4*>(
                         xb + (size_t)t * C + co);
                     if (mode == 2)
@@ -430,10 +462,10 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int co = co_base + 8 * g4;
                     float4 v;
-                    v.x = acc[mt][nt][4 * g4 + 0] + bias[g4].x + res[g4].x;
-                    v.y = acc[mt][nt][4 * g4 + 1] + bias[g4].y + res[g4].y;
-                    v.z = acc[mt][nt][4 * g4 + 2] + bias[g4].z + res[g4].z;
-                    v.w = acc[mt][nt][4 * g4 + 3] + bias[g4].w + res[g4].w;
+                    v.x = acc[mt][nt][4 * g4 + 0] + res[g4].x;
+                    v.y = acc[mt][nt][4 * g4 + 1] + res[g4].y;
+                    v.z = acc[mt][nt][4 * g4 + 2] + res[g4].z;
+                    v.w = acc[mt][nt][4 * g4 + 3] + res[g4].w;
                     if (mode == 1) {
                         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
                     } else if (mode == 2) {
@@ -700,7 +732,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int m_first = wm * MTW * 32;     // this wave's first channel
     const int ln = lane & 31, lh = lane >> 5;
@@ -712,6 +744,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
     if (tile * a.TL >= L) return;
     const int c_first = tile * a.TL - a.halo;   // time of column 0
     const float* __restrict__ xb = a.x + (size_t)b * a.L * C;
+    PM_STAMP(a, 0);
 
     // ---- zero the margins (they stand for neighbours' columns: only ever
     // feed the recomputed halo, but must be finite) ------------------------
@@ -783,9 +816,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
             }
         }
     __syncthreads();
+    PM_STAMP(a, 1);
 
     const int col_off = (wn * NTW * 32 + ln) * S + lh * 8 * ET::ESZ;
     floatx16 acc[MTW][NTW];
+    floatx16 bv[MTW];
+    load_bias_vec<MTW>(bv, a.b1[0], m_first + 4 * lh);
+    init_acc<MTW, NTW>(acc, bv);
     frag_t afirst[G][MTW];
     load_a_group<ET, MTW, G>(
         afirst, reinterpret_cast<const frag_t*>(a.w1[0]) +
@@ -798,46 +835,47 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
                            (size_t)(wm * MTW) * W_MT_STRIDE + lane;
         const frag_t* w2 = reinterpret_cast<const frag_t*>(a.w2[it]) +
                            (size_t)(wm * MTW) * W_MT_STRIDE + lane;
-        const float* b1 = a.b1[it];
-        const float* b2 = a.b2[it];
 
         // ---- conv1 (dilation d) out of `a` ----
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c)
             mma_taps<ET, K, KC, MTW, NTW, G, S>(
                 acc, abuf + (MA - H2 * d) * S + col_off + c * CH * ET::ESZ,
                 d * S, w1 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
                 c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
+        PM_STAMP(a, 2 + 4 * it);
+        load_bias_vec<MTW>(bv, a.b2[it], m_first + 4 * lh);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                const int col = (wn * NTW + nt) * 32 + ln;
-                const int t = c_first + col;
-                const bool inside = t >= 0 && t < L;
+                const int col_first = (wn * NTW + nt) * 32;
+                const int col = col_first + ln;
+                const int t_tile = c_first + col_first;
+                if (t_tile >= 0 && t_tile + 32 <= L) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int co = m_first + mt * 32 + 8 * g4 + 4 * lh;
-                    const float4 bias =
-                        *reinterpret_cast<const float4*>(b1 + co);
-                    float4 v;
-                    v.x = pm_lrelu(acc[mt][nt][4 * g4 + 0] + bias.x);
-                    v.y = pm_lrelu(acc[mt][nt][4 * g4 + 1] + bias.y);
-                    v.z = pm_lrelu(acc[mt][nt][4 * g4 + 2] + bias.z);
-                    v.w = pm_lrelu(acc[mt][nt][4 * g4 + 3] + bias.w);
-                    if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    ET::store4(tbuf + (H2 + col) * S + co * ET::ESZ, v);
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        ET::store4(
+                            tbuf + (H2 + col) * S +
+                                (m_first + mt * 32 + 8 * g4 + 4 * lh) * ET::ESZ,
+                            pm_lrelu4(acc_quad(acc[mt][nt], g4)));
+                } else {
+                    const int t = t_tile + ln;
+                    const bool inside = t >= 0 && t < L;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[mt][nt][4 * g4 + r] = 0.f;
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        float4 v = pm_lrelu4(acc_quad(acc[mt][nt], g4));
+                        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        ET::store4(
+                            tbuf + (H2 + col) * S +
+                                (m_first + mt * 32 + 8 * g4 + 4 * lh) * ET::ESZ,
+                            v);
+                    }
                 }
             }
+        init_acc<MTW, NTW>(acc, bv);
         __syncthreads();
+        PM_STAMP(a, 3 + 4 * it);
 
         // ---- conv2 (dilation 1) out of `t`, residual into the trunk ----
         const bool last = it + 1 == a.niter;
@@ -851,36 +889,44 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
                     : (last ? nullptr
                             : reinterpret_cast<const frag_t*>(a.w1[it + 1]) +
                                   (size_t)(wm * MTW) * W_MT_STRIDE + lane));
+        PM_STAMP(a, 4 + 4 * it);
+        if (!last) load_bias_vec<MTW>(bv, a.b1[it + 1], m_first + 4 * lh);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                const int col = (wn * NTW + nt) * 32 + ln;
-                const int t = c_first + col;
-                const bool inside = t >= 0 && t < L;
+                trunk[mt][nt] += acc[mt][nt];
+                if (!last) {
+                    const int col_first = (wn * NTW + nt) * 32;
+                    const int col = col_first + ln;
+                    const int t_tile = c_first + col_first;
+                    if (t_tile >= 0 && t_tile + 32 <= L) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int co = m_first + mt * 32 + 8 * g4 + 4 * lh;
-                    const float4 bias =
-                        *reinterpret_cast<const float4*>(b2 + co);
-                    float4 v;
-                    v.x = trunk[mt][nt][4 * g4 + 0] + acc[mt][nt][4 * g4 + 0] + bias.x;
-                    v.y = trunk[mt][nt][4 * g4 + 1] + acc[mt][nt][4 * g4 + 1] + bias.y;
-                    v.z = trunk[mt][nt][4 * g4 + 2] + acc[mt][nt][4 * g4 + 2] + bias.z;
-                    v.w = trunk[mt][nt][4 * g4 + 3] + acc[mt][nt][4 * g4 + 3] + bias.w;
-                    trunk[mt][nt][4 * g4 + 0] = v.x;
-                    trunk[mt][nt][4 * g4 + 1] = v.y;
-                    trunk[mt][nt][4 * g4 + 2] = v.z;
-                    trunk[mt][nt][4 * g4 + 3] = v.w;
-                    if (!last) {
-                        v.x = pm_lrelu(v.x); v.y = pm_lrelu(v.y);
-                        v.z = pm_lrelu(v.z); v.w = pm_lrelu(v.w);
-                        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        ET::store4(abuf + (MA + col) * S + co * ET::ESZ, v);
+                        for (int g4 = 0; g4 < 4; ++g4)
+                            ET::store4(
+                                abuf + (MA + col) * S +
+                                    (m_first + mt * 32 + 8 * g4 + 4 * lh) *
+                                        ET::ESZ,
+                                pm_lrelu4(acc_quad(trunk[mt][nt], g4)));
+                    } else {
+                        const int t = t_tile + ln;
+                        const bool inside = t >= 0 && t < L;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            float4 v = pm_lrelu4(acc_quad(trunk[mt][nt], g4));
+                            if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            ET::store4(
+                                abuf + (MA + col) * S +
+                                    (m_first + mt * 32 + 8 * g4 + 4 * lh) *
+                                        ET::ESZ,
+                                v);
+                        }
                     }
                 }
             }
+        if (!last) init_acc<MTW, NTW>(acc, bv);
         if (!last) __syncthreads();
+        PM_STAMP(a, 5 + 4 * it);
     }
 
     // ---- store the valid interior (+ MRF accumulate) ----------------------
@@ -923,4 +969,5 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
                 }
             }
         }
+    PM_STAMP(a, 14);
 }

@@ -4,7 +4,7 @@
 set -e
 cd $(dirname $0)/..
 SUF=$1; shift
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-value $*"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-value -fno-honor-nans $*"
 mkdir -p build/obj_$SUF
 for f in pm_api pm_conv_f16 pm_conv_bf16 pm_conv_f32; do
   /opt/rocm/bin/hipcc $F -c promonet_amd/csrc/$f.hip -o build/obj_$SUF/$f.o &
