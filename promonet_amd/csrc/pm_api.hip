@@ -75,14 +75,28 @@ static hipError_t launch_block3(
     return hipErrorInvalidValue;
 }
 
-// PM_FUSION=pair forces one kernel per Block iteration everywhere (A/B runs)
-static bool block3_enabled() {
-    static int enabled = -1;
-    if (enabled < 0) {
-        const char* e = getenv("PM_FUSION");
-        enabled = (e && !strcmp(e, "pair")) ? 0 : 1;
+static hipError_t launch_mrf(
+    int dtype, int C, const Block3Args (&a)[3], hipStream_t s) {
+    switch (dtype) {
+        case PM_F32: return pm_launch_mrf<ElemF32>(C, a, s);
+        case PM_F16: return pm_launch_mrf<ElemF16>(C, a, s);
+        case PM_BF16: return pm_launch_mrf<ElemBF16>(C, a, s);
     }
-    return enabled == 1;
+    return hipErrorInvalidValue;
+}
+
+// PM_FUSION=pair forces one kernel per Block iteration everywhere, =block one
+// kernel per Block (no whole-MRF launch) (A/B runs)
+static int fusion_level() {
+    static int level = -1;
+    if (level < 0) {
+        const char* e = getenv("PM_FUSION");
+        level = (e && !strcmp(e, "pair")) ? 0 : (e && !strcmp(e, "block")) ? 1 : 2;
+    }
+    return level;
+}
+static bool block3_enabled() {
+    return fusion_level() >= 1;
 }
 
 static int pair_chunk(int dtype, int C) {
@@ -642,7 +656,40 @@ static int forward_impl(
         L *= st.r;
         rate *= st.r;
         const int si = xi;   // stage input is dead after the upsampler
-        for (int j = 0; j < h->cfg.num_resblocks; ++j) {
+        // whole MRF (Blocks k = 3, 7, 11) in one launch: U -> S
+        bool mrf_done = false;
+        if (fusion_level() >= 2 && h->cfg.num_resblocks == 3 &&
+            h->cfg.num_dilations <= 3 && st.cout_pad <= 64 &&
+            h->cfg.resblock_kernel_sizes[0] == 3 &&
+            h->cfg.resblock_kernel_sizes[1] == 7 &&
+            h->cfg.resblock_kernel_sizes[2] == 11) {
+            Block3Args blocks[3] = {};
+            double flops = 0;
+            for (int j = 0; j < 3; ++j) {
+                Block3Args& a = blocks[j];
+                a.x = buf[ui]; a.out = buf[si];
+                a.niter = h->cfg.num_dilations;
+                for (int n = 0; n < a.niter; ++n) {
+                    a.w1[n] = st.c1[j][n].w; a.b1[n] = st.c1[j][n].bias;
+                    a.w2[n] = st.c2[j][n].w; a.b2[n] = st.c2[j][n].bias;
+                    a.dil[n] = h->cfg.resblock_dilations[j][n];
+                    flops += 4.0 * st.cout * st.cout *
+                             h->cfg.resblock_kernel_sizes[j] * B * L;
+                }
+                a.B = B; a.L = L; a.mode = j == 0 ? 1 : 2; a.scale = scale;
+                a.lengths = lengths; a.len_scale = rate;
+            }
+            char label[64];
+            snprintf(label, sizeof(label), "mrf_c%d", st.cout);
+            hipError_t e = hipSuccess;
+            PROF(h, s, label, flops, (double)B * L * st.cout * 4 * 2, {
+                e = launch_mrf(h->dtype, st.cout_pad, blocks, s);
+                if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
+            });
+            mrf_done = e == hipSuccess;
+            if (!mrf_done && h->profile) h->marks.pop_back();
+        }
+        for (int j = 0; !mrf_done && j < h->cfg.num_resblocks; ++j) {
             const int K = h->cfg.resblock_kernel_sizes[j];
             bool fused = false;
             if (h->cfg.num_dilations <= 3 &&

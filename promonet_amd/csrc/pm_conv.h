@@ -708,8 +708,7 @@ __host__ __device__ constexpr int block3_smem_bytes() {
 }
 
 template <class ET, int C, int K, int WM, int WN, int NTW>
-__global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
-    Block3Args a) {
+__device__ __forceinline__ void block3_body(const Block3Args& a, char* smem) {
     typedef typename ET::frag_t frag_t;
     constexpr int CH = C < 64 ? C : 64;    // weight-stream chunk (as packed)
     constexpr int NCH = C / CH;
@@ -726,7 +725,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_MT_STRIDE = NCH * W_CHUNK;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* abuf = smem;
     char* tbuf = smem + ROWS_A * S;
 
@@ -762,40 +760,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
             *reinterpret_cast<float4*>(tbuf + row * S + q * 16) = z;
         }
     }
-    // ---- stage a = lrelu(x) (coalesced), zero outside the utterance ------
-    // loads first, LDS writes after: a load-use-per-iteration loop is one
-    // HBM round trip per iteration
-    {
-        constexpr int Q = C / 4;
-        constexpr int ITER = (NC * Q + NT - 1) / NT;
-        constexpr int BATCH = ITER < 12 ? ITER : 12;
-#pragma unroll 1
-        for (int i0 = 0; i0 < ITER; i0 += BATCH) {
-            float4 v[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int i = tid + (i0 + u) * NT;
-                const int col = i / Q, q = i % Q;
-                const int t = c_first + col;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i0 + u < ITER && col < NC && t >= 0 && t < L)
-                    v[u] = *reinterpret_cast<const float4*>(
-                        xb + (size_t)t * C + q * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int i = tid + (i0 + u) * NT;
-                const int col = i / Q, q = i % Q;
-                if (i0 + u < ITER && col < NC) {
-                    float4 w4 = v[u];
-                    w4.x = pm_lrelu(w4.x); w4.y = pm_lrelu(w4.y);
-                    w4.z = pm_lrelu(w4.z); w4.w = pm_lrelu(w4.w);
-                    ET::store4(abuf + (MA + col) * S + q * 4 * ET::ESZ, w4);
-                }
-            }
-        }
-    }
-    // ---- trunk registers <- x in the MFMA C/D layout ----------------------
+    // ---- trunk registers <- x in the MFMA C/D layout (zero outside the
+    // utterance), and a = lrelu(x) -> LDS out of the same registers: the
+    // workgroup's NC columns are exactly its waves' tiles, so x is read from
+    // HBM once. All loads are issued before the first LDS write.
     floatx16 trunk[MTW][NTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -814,6 +782,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
                 trunk[mt][nt][4 * g4 + 2] = v.z;
                 trunk[mt][nt][4 * g4 + 3] = v.w;
             }
+        }
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int col = (wn * NTW + nt) * 32 + ln;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                ET::store4(
+                    abuf + (MA + col) * S +
+                        (m_first + mt * 32 + 8 * g4 + 4 * lh) * ET::ESZ,
+                    pm_lrelu4(acc_quad(trunk[mt][nt], g4)));
         }
     __syncthreads();
     PM_STAMP(a, 1);
@@ -970,4 +950,30 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
             }
         }
     PM_STAMP(a, 14);
+}
+
+template <class ET, int C, int K, int WM, int WN, int NTW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
+    Block3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    block3_body<ET, C, K, WM, WN, NTW>(a, smem);
+}
+
+// Whole MRF stage (the three Blocks k = 3, 7, 11 of one upsampling stage,
+// generator.py MRF: out = (B3(x) + B7(x) + B11(x)) / 3) in one launch: a
+// workgroup runs the three Blocks back to back on ITS tile with the k = 11
+// tiling, so the re-reads of x and the read-modify-write of `out` by the
+// second and third Block find the lines this same workgroup just touched in
+// L2 instead of sweeping HBM three times per Block. Same lanes touch the same
+// addresses in every phase: program order is the only ordering needed.
+struct MrfArgs { Block3Args k[3]; };
+
+template <class ET, int C, int WM, int WN, int NTW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_mrf_kernel(MrfArgs m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    block3_body<ET, C, 3, WM, WN, NTW>(m.k[0], smem);
+    __syncthreads();
+    block3_body<ET, C, 7, WM, WN, NTW>(m.k[1], smem);
+    __syncthreads();
+    block3_body<ET, C, 11, WM, WN, NTW>(m.k[2], smem);
 }

@@ -17,6 +17,11 @@ template <class ET> bool pm_block3_supported(int C, int K);
 template <class ET> hipError_t pm_launch_block3(
     int C, int K, const Block3Args& args, hipStream_t stream);
 
+// Whole MRF stage (Blocks k = 3, 7, 11 in that order) in one launch for
+// C <= 64; hipErrorNotSupported otherwise (caller launches Block by Block).
+template <class ET> hipError_t pm_launch_mrf(
+    int C, const Block3Args (&blocks)[3], hipStream_t stream);
+
 // kind 0: plain conv with KT = KSPAN = 7 (input conv); kind 1: polyphase
 // ConvTranspose (KT = 2, KSPAN = 3). cfg: 0 = 256 x 128 tile, 1 = 64 x 128,
 // 2 = 32 x 128.
@@ -137,13 +142,26 @@ int pm_pair_chunk(int C) {
 // the column count so that two workgroups share a CU is SLOWER (C = 64 k 3:
 // 1.65 vs 1.22 ms), so every shape takes the widest tile LDS allows.
 template <class ET, int C, int K> struct Block3Cfg { enum { WM = 0, WN = 1, NTW = 1 }; };
+#ifdef PM_B32_HALF   // A/B: two 4-wave workgroups per CU, same per-wave work
+template <> struct Block3Cfg<ElemF16, 32, 3>   { enum { WM = 1, WN = 4, NTW = 3 }; };
+template <> struct Block3Cfg<ElemF16, 32, 7>   { enum { WM = 1, WN = 4, NTW = 3 }; };
+#else
 template <> struct Block3Cfg<ElemF16, 32, 3>   { enum { WM = 1, WN = 8, NTW = 3 }; };
 template <> struct Block3Cfg<ElemF16, 32, 7>   { enum { WM = 1, WN = 8, NTW = 3 }; };
+#endif
+#ifdef PM_B_HALF2
+template <> struct Block3Cfg<ElemF16, 32, 11>  { enum { WM = 1, WN = 4, NTW = 3 }; };
+template <> struct Block3Cfg<ElemF16, 64, 3>   { enum { WM = 2, WN = 2, NTW = 4 }; };
+template <> struct Block3Cfg<ElemF16, 64, 7>   { enum { WM = 2, WN = 2, NTW = 4 }; };
+template <> struct Block3Cfg<ElemF16, 64, 11>  { enum { WM = 2, WN = 4, NTW = 4 }; };
+template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 1, NTW = 4 }; };
+#else
 template <> struct Block3Cfg<ElemF16, 32, 11>  { enum { WM = 1, WN = 8, NTW = 3 }; };
 template <> struct Block3Cfg<ElemF16, 64, 3>   { enum { WM = 2, WN = 4, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 64, 7>   { enum { WM = 2, WN = 4, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 64, 11>  { enum { WM = 2, WN = 4, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 2, NTW = 4 }; };
+#endif
 template <int C, int K> struct Block3Cfg<ElemBF16, C, K> : Block3Cfg<ElemF16, C, K> {};
 template <> struct Block3Cfg<ElemF32, 32, 3>   { enum { WM = 1, WN = 8, NTW = 2 }; };
 template <> struct Block3Cfg<ElemF32, 32, 7>   { enum { WM = 1, WN = 8, NTW = 2 }; };
@@ -188,6 +206,65 @@ static hipError_t launch_block3_c(int K, const Block3Args& a, hipStream_t s) {
         case 3: return launch_block3_ck<ET, C, 3>(a, s);
         case 7: return launch_block3_ck<ET, C, 7>(a, s);
         case 11: return launch_block3_ck<ET, C, 11>(a, s);
+    }
+    return hipErrorNotSupported;
+}
+
+// Whole-MRF launch: kernel sizes (3, 7, 11), the k = 11 tiling for all three.
+template <class ET, int C>
+static hipError_t launch_mrf_c(const Block3Args (&blocks)[3], hipStream_t stream) {
+    typedef Block3Cfg<ET, C, 11> G;
+    if constexpr (G::WM == 0 || Block3Cfg<ET, C, 3>::WM == 0 ||
+                  Block3Cfg<ET, C, 7>::WM == 0) {
+        return hipErrorNotSupported;
+    } else {
+    constexpr int WM = G::WM, WN = G::WN, NTW = G::NTW;
+    constexpr int NC = WN * NTW * 32;
+    MrfArgs m;
+    int halo = 0;
+    constexpr int KS[3] = {3, 7, 11};
+    for (int j = 0; j < 3; ++j) {
+        m.k[j] = blocks[j];
+        int h = 0;
+        for (int i = 0; i < m.k[j].niter; ++i)
+            h += (m.k[j].dil[i] + 1) * ((KS[j] - 1) / 2);
+        halo = h > halo ? h : halo;
+    }
+    const int TL = NC - 2 * halo;
+    if (TL < 32) return hipErrorNotSupported;
+    for (int j = 0; j < 3; ++j) {
+        m.k[j].halo = halo; m.k[j].TL = TL;
+        m.k[j].ntiles = (m.k[j].L + TL - 1) / TL;
+        m.k[j].timeline = nullptr;
+    }
+    auto kern = conv_mrf_kernel<ET, C, WM, WN, NTW>;
+    constexpr int smem = block3_smem_bytes<ET, C, 11, WM, WN, NTW>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(kern),
+            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(m.k[0].ntiles * m.k[0].B),
+                       dim3(WM * WN * 64), smem, stream, m);
+    return hipGetLastError();
+    }
+}
+
+template <class ET>
+hipError_t pm_launch_mrf(int C, const Block3Args (&blocks)[3], hipStream_t s) {
+    for (int j = 0; j < 3; ++j) {
+        if (blocks[j].niter < 1 || blocks[j].niter > 3)
+            return hipErrorNotSupported;
+        for (int i = 0; i < blocks[j].niter; ++i)
+            if (blocks[j].dil[i] < 1 || blocks[j].dil[i] > 5)
+                return hipErrorNotSupported;
+    }
+    switch (C) {
+        case 64: return launch_mrf_c<ET, 64>(blocks, s);
+        case 32: return launch_mrf_c<ET, 32>(blocks, s);
     }
     return hipErrorNotSupported;
 }
