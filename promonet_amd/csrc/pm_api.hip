@@ -746,13 +746,23 @@ static int forward_impl(
     {
         constexpr int TH = 256;
         const int C = h->c_last_pad;
-        const size_t smem = ((size_t)(TH + 6) * (C + 1) + 7 * C) * sizeof(float);
         PROF(h, s, "out_conv_tanh", 2.0 * h->c_last * 7 * B * L,
              (double)B * L * (h->c_last + 1) * 4, {
-            hipLaunchKernelGGL(pm_out_conv_kernel<TH>,
-                               dim3((L + TH - 1) / TH, B), dim3(TH), smem, s,
-                               buf[xi], h->out_w, out, L, C, h->c_last,
-                               lengths, rate);
+            if (C == 32 && h->c_last == 32) {
+                constexpr int T32 = 128;   // 38 KB of LDS: four per CU
+                const size_t smem = (size_t)32 * (PM_OUT32_RL(T32) + 8) * sizeof(float);
+                hipLaunchKernelGGL(pm_out_conv32_kernel<T32>,
+                                   dim3((L + T32 * 2 - 1) / (T32 * 2), B),
+                                   dim3(T32), smem, s, buf[xi], h->out_w, out,
+                                   L, lengths, rate);
+            } else {
+                const size_t smem =
+                    ((size_t)(TH + 6) * (C + 1) + 7 * C) * sizeof(float);
+                hipLaunchKernelGGL(pm_out_conv_kernel<TH>,
+                                   dim3((L + TH - 1) / TH, B), dim3(TH), smem,
+                                   s, buf[xi], h->out_w, out, L, C, h->c_last,
+                                   lengths, rate);
+            }
             HIP_TRY(hipGetLastError());
         });
     }

@@ -707,8 +707,13 @@ __host__ __device__ constexpr int block3_smem_bytes() {
     return (NC + 10 * ((K - 1) / 2)) * S + (NC + (K - 1)) * S;
 }
 
-template <class ET, int C, int K, int WM, int WN, int NTW>
-__device__ __forceinline__ void block3_body(const Block3Args& a, char* smem) {
+// SUM: 0 = stand-alone Block (store per a.mode); inside a whole-MRF launch
+// with the sum of the Blocks held in registers: 1 = first Block (sum = y),
+// 2 = middle (sum += y), 3 = last (store (sum + y) * scale).
+template <class ET, int C, int K, int WM, int WN, int NTW, int SUM = 0>
+__device__ __forceinline__ void block3_body(
+    const Block3Args& a, char* smem,
+    floatx16 (&sum)[(C / 32) / WM][NTW]) {
     typedef typename ET::frag_t frag_t;
     constexpr int CH = C < 64 ? C : 64;    // weight-stream chunk (as packed)
     constexpr int NCH = C / CH;
@@ -909,9 +914,25 @@ __device__ __forceinline__ void block3_body(const Block3Args& a, char* smem) {
         PM_STAMP(a, 5 + 4 * it);
     }
 
+    if constexpr (SUM == 1 || SUM == 2) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                if (SUM == 1) sum[mt][nt] = trunk[mt][nt];
+                else sum[mt][nt] += trunk[mt][nt];
+            }
+        return;
+    }
+    if constexpr (SUM == 3) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) trunk[mt][nt] += sum[mt][nt];
+    }
     // ---- store the valid interior (+ MRF accumulate) ----------------------
     float* __restrict__ ob = a.out + (size_t)b * a.L * C;
-    const int mode = a.mode;
+    const int mode = SUM == 3 ? 1 : a.mode;
     const float scale = a.scale;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -956,7 +977,8 @@ template <class ET, int C, int K, int WM, int WN, int NTW>
 __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
     Block3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    block3_body<ET, C, K, WM, WN, NTW>(a, smem);
+    floatx16 unused[(C / 32) / WM][NTW];
+    block3_body<ET, C, K, WM, WN, NTW>(a, smem, unused);
 }
 
 // Whole MRF stage (the three Blocks k = 3, 7, 11 of one upsampling stage,
@@ -968,12 +990,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
 // addresses in every phase: program order is the only ordering needed.
 struct MrfArgs { Block3Args k[3]; };
 
-template <class ET, int C, int WM, int WN, int NTW>
+template <class ET, int C, int WM, int WN, int NTW, bool INREG>
 __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_kernel(MrfArgs m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    block3_body<ET, C, 3, WM, WN, NTW>(m.k[0], smem);
-    __syncthreads();
-    block3_body<ET, C, 7, WM, WN, NTW>(m.k[1], smem);
-    __syncthreads();
-    block3_body<ET, C, 11, WM, WN, NTW>(m.k[2], smem);
+    floatx16 sum[(C / 32) / WM][NTW];
+    if constexpr (INREG) {
+        // the sum of the Blocks stays in registers (no read-modify-write of
+        // `out`); k = 11 first: its MFMA loop has the highest register
+        // pressure and runs before the sum is live
+        block3_body<ET, C, 11, WM, WN, NTW, 1>(m.k[2], smem, sum);
+        __syncthreads();
+        block3_body<ET, C, 7, WM, WN, NTW, 2>(m.k[1], smem, sum);
+        __syncthreads();
+        block3_body<ET, C, 3, WM, WN, NTW, 3>(m.k[0], smem, sum);
+    } else {
+        block3_body<ET, C, 3, WM, WN, NTW>(m.k[0], smem, sum);
+        __syncthreads();
+        block3_body<ET, C, 7, WM, WN, NTW>(m.k[1], smem, sum);
+        __syncthreads();
+        block3_body<ET, C, 11, WM, WN, NTW>(m.k[2], smem, sum);
+    }
 }

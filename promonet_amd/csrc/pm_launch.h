@@ -237,7 +237,7 @@ static hipError_t launch_mrf_c(const Block3Args (&blocks)[3], hipStream_t stream
         m.k[j].ntiles = (m.k[j].L + TL - 1) / TL;
         m.k[j].timeline = nullptr;
     }
-    auto kern = conv_mrf_kernel<ET, C, WM, WN, NTW>;
+    auto kern = conv_mrf_kernel<ET, C, WM, WN, NTW, C == 32>;
     constexpr int smem = block3_smem_bytes<ET, C, 11, WM, WN, NTW>();
     static bool attr_set = false;
     if (!attr_set) {

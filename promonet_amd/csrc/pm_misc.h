@@ -318,6 +318,96 @@ __global__ __launch_bounds__(THREADS) void pm_out_conv_kernel(
     y[(size_t)b * Lmax + t] = tanhf(acc);
 }
 
+// channel-row length of pm_out_conv32_kernel: >= tile + halo + window slack,
+// even (8-byte window reads), = 10 mod 32 (staging writes 2-way at worst)
+#define PM_OUT32_RL(threads) ((((threads) * 2 + 8 + 31) / 32) * 32 + 10)
+
+// Same layer for the default 32-channel last stage, restructured around what
+// bounds it: the generic kernel reads LDS twice per FMA (activation + weight).
+// Here the tile sits channel-major in LDS and every thread produces two
+// consecutive samples from an 8-sample register window per channel: four
+// conflict-free ds_read_b64 of activations and two broadcast ds_read_b128 of
+// weights feed 14 FMAs. (Weights as scalar loads: the compiler hoists all 224
+// and spills SGPRs through v_readlane - 2x slower.)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void pm_out_conv32_kernel(
+    const float* __restrict__ x, const float* __restrict__ w,
+    float* __restrict__ y, int Lmax, const int* __restrict__ lengths,
+    int len_scale) {
+    constexpr int C = 32, KW = 7, HALO = 3, PT = 2;
+    constexpr int TILE = THREADS * PT;
+    constexpr int ROWS = TILE + 2 * HALO;
+    constexpr int RL = PM_OUT32_RL(THREADS);  // floats per channel row
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [C][RL]
+    float* wsm = sm + C * RL;                 // [C][8]: 7 taps + pad
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TILE;
+    const int L = lengths ? min(lengths[b] * len_scale, Lmax) : Lmax;
+    float* yb = y + (size_t)b * Lmax;
+    if (t0 >= L) {
+        for (int i = threadIdx.x; i < TILE; i += THREADS)
+            if (t0 + i < Lmax) yb[t0 + i] = 0.f;
+        return;
+    }
+    for (int i = threadIdx.x; i < C * 8; i += THREADS)
+        wsm[i] = (i & 7) < KW ? w[(i >> 3) * KW + (i & 7)] : 0.f;
+    const float* xb = x + (size_t)b * Lmax * C;
+    constexpr int Q = C / 4;
+    // every load of the tile is in flight before the first LDS write (a
+    // load-use-per-iteration loop is one HBM round trip per iteration)
+    constexpr int ITER = (ROWS * Q + THREADS - 1) / THREADS;
+    float4 v[ITER];
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) {
+        const int i = threadIdx.x + u * THREADS;
+        const int row = i / Q, q = i % Q;
+        const int t = t0 - HALO + row;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < ROWS && t >= 0 && t < L)
+            v[u] = *reinterpret_cast<const float4*>(xb + (size_t)t * C + q * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) {
+        const int i = threadIdx.x + u * THREADS;
+        const int row = i / Q, q = i % Q;
+        if (row < ROWS) {
+            const float4 r = pm_lrelu4(v[u]);
+            sm[(q * 4 + 0) * RL + row] = r.x;
+            sm[(q * 4 + 1) * RL + row] = r.y;
+            sm[(q * 4 + 2) * RL + row] = r.z;
+            sm[(q * 4 + 3) * RL + row] = r.w;
+        }
+    }
+    __syncthreads();
+    const int first = threadIdx.x * PT;      // window rows first .. first + 7
+    float acc[PT] = {0.f, 0.f};
+    // (fully unrolled, the scheduler hoists every LDS read of all 32
+    // channels: 512 VGPRs and spills)
+#pragma unroll 2
+    for (int c = 0; c < C; ++c) {
+        float win[PT + KW - 1];
+#pragma unroll
+        for (int r = 0; r < PT + KW - 1; r += 2) {
+            const float2 v =
+                *reinterpret_cast<const float2*>(sm + c * RL + first + r);
+            win[r] = v.x; win[r + 1] = v.y;
+        }
+        const float4 wa = *reinterpret_cast<const float4*>(wsm + c * 8);
+        const float4 wb = *reinterpret_cast<const float4*>(wsm + c * 8 + 4);
+        const float wj[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+        for (int j = 0; j < KW; ++j)
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+                acc[p] = fmaf(wj[j], win[p + j], acc[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int t = t0 + first + p;
+        if (t < Lmax) yb[t] = t < L ? tanhf(acc[p]) : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // promonet.edit: 1-D grid sampling of a frame
 // sequence (edit/grid.py:12-45) with the per-feature post-ops of
