@@ -186,6 +186,7 @@ static hipError_t pad_bias(
 
 static int single_cfg(int M, int ch, int wave64_ok) {
     if (M % 256 == 0 && ch == 64 && wave64_ok) return 0;
+    if (M == 128 && ch == 64) return 3;   // whole M in one workgroup
     if (M % 64 == 0) return 1;
     return 2;
 }

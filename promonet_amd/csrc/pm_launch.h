@@ -24,6 +24,7 @@ template <class ET> hipError_t pm_launch_mrf(
 
 // kind 0: plain conv with KT = KSPAN = 7 (input conv); kind 1: polyphase
 // ConvTranspose (KT = 2, KSPAN = 3). cfg: 0 = 256 x 128 tile, 1 = 64 x 128,
+// 3 = 128 x 128 (measured: a 512 x 128 tile is 20 % slower than cfg 0),
 // 2 = 32 x 128.
 template <class ET> hipError_t pm_launch_single(
     int kind, int ch, int cfg, const SingleArgs& args, hipStream_t stream);
@@ -334,6 +335,8 @@ static hipError_t launch_single_k(
             case 0: return launch_single_cfg<ET, KT, KSPAN, 64, 4, 2, 2, 2>(a, s);
             case 1: return launch_single_cfg<ET, KT, KSPAN, 64, 2, 2, 1, 2>(a, s);
             case 2: return launch_single_cfg<ET, KT, KSPAN, 64, 1, 4, 1, 1>(a, s);
+            // all 128 rows of a 2x upsampler in one workgroup: x is read once
+            case 3: return launch_single_cfg<ET, KT, KSPAN, 64, 4, 2, 1, 2>(a, s);
         }
     } else if (ch == 32) {
         switch (cfg) {
