@@ -24,10 +24,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float pm_lrelu(float v) {
     return __builtin_fmaxf(v, v * PM_LRELU_SLOPE);
 }
+// four at once on vector types: two v_pk_mul_f32 + four v_max_f32
+typedef float pm_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 pm_lrelu4(float4 v) {
-    v.x = pm_lrelu(v.x); v.y = pm_lrelu(v.y);
-    v.z = pm_lrelu(v.z); v.w = pm_lrelu(v.w);
-    return v;
+    pm_f4 w = {v.x, v.y, v.z, v.w};
+    w = __builtin_elementwise_max(w, w * PM_LRELU_SLOPE);
+    return make_float4(w.x, w.y, w.z, w.w);
 }
 
 // ---------------------------------------------------------------------------
@@ -49,8 +51,9 @@ struct ElemF16 {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
     __device__ static __forceinline__ void store4(char* p, float4 v) {
-        half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        *reinterpret_cast<half4*>(p) = h;
+        // vector conversion: two v_cvt_pk_f16_f32 (round to nearest even)
+        const pm_f4 w = {v.x, v.y, v.z, v.w};
+        *reinterpret_cast<half4*>(p) = __builtin_convertvector(w, half4);
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return (_Float16)v; }
 };
@@ -65,8 +68,8 @@ struct ElemBF16 {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
     __device__ static __forceinline__ void store4(char* p, float4 v) {
-        bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        *reinterpret_cast<bf16x4*>(p) = h;
+        const pm_f4 w = {v.x, v.y, v.z, v.w};
+        *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(w, bf16x4);
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return (__bf16)v; }
 };

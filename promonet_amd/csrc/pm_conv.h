@@ -62,12 +62,8 @@ struct ChunkStager {
             const int idx = tid + it * NT;
             const int row = idx / Q, q = idx % Q;
             if (row < XR) {
-                float4 v = r[it];
-                if (LRELU) {
-                    v.x = pm_lrelu(v.x); v.y = pm_lrelu(v.y);
-                    v.z = pm_lrelu(v.z); v.w = pm_lrelu(v.w);
-                }
-                ET::store4(buf + row * S + q * 4 * ET::ESZ, v);
+                ET::store4(buf + row * S + q * 4 * ET::ESZ,
+                           LRELU ? pm_lrelu4(r[it]) : r[it]);
             }
         }
     }
