@@ -140,29 +140,22 @@ int pm_pair_chunk(int C) {
 // ---- whole-Block fusion ---------------------------------------------------
 // Geometry per (operand type, C, K). WM == 0: no whole-Block instantiation
 // (the caller runs one pair kernel per iteration instead). Measured: halving
-// the column count so that two workgroups share a CU is SLOWER (C = 64 k 3:
-// 1.65 vs 1.22 ms), so every shape takes the widest tile LDS allows.
+// the columns PER WAVE so that two workgroups share a CU is slower (C = 64
+// k 3: 1.65 vs 1.22 ms - the fixed cost per barrier phase dominates), so a
+// wave always keeps the widest register tile.
 template <class ET, int C, int K> struct Block3Cfg { enum { WM = 0, WN = 1, NTW = 1 }; };
-#ifdef PM_B32_HALF   // A/B: two 4-wave workgroups per CU, same per-wave work
+// Small k (halo <= 36 columns): two 4-wave workgroups per CU with the same
+// per-wave work beat one 8-wave workgroup (their phases interleave): -14 %
+// at C = 32 k 3, -5 % at C = 32 k 7, -13 % at C = 64 k 3. With a larger halo
+// (k 11, or k 7 at C = 64) the extra recompute eats the gain; at C = 128 it is
+// 28 % slower.
 template <> struct Block3Cfg<ElemF16, 32, 3>   { enum { WM = 1, WN = 4, NTW = 3 }; };
 template <> struct Block3Cfg<ElemF16, 32, 7>   { enum { WM = 1, WN = 4, NTW = 3 }; };
-#else
-template <> struct Block3Cfg<ElemF16, 32, 3>   { enum { WM = 1, WN = 8, NTW = 3 }; };
-template <> struct Block3Cfg<ElemF16, 32, 7>   { enum { WM = 1, WN = 8, NTW = 3 }; };
-#endif
-#ifdef PM_B_HALF2
-template <> struct Block3Cfg<ElemF16, 32, 11>  { enum { WM = 1, WN = 4, NTW = 3 }; };
-template <> struct Block3Cfg<ElemF16, 64, 3>   { enum { WM = 2, WN = 2, NTW = 4 }; };
-template <> struct Block3Cfg<ElemF16, 64, 7>   { enum { WM = 2, WN = 2, NTW = 4 }; };
-template <> struct Block3Cfg<ElemF16, 64, 11>  { enum { WM = 2, WN = 4, NTW = 4 }; };
-template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 1, NTW = 4 }; };
-#else
 template <> struct Block3Cfg<ElemF16, 32, 11>  { enum { WM = 1, WN = 8, NTW = 3 }; };
-template <> struct Block3Cfg<ElemF16, 64, 3>   { enum { WM = 2, WN = 4, NTW = 4 }; };
+template <> struct Block3Cfg<ElemF16, 64, 3>   { enum { WM = 2, WN = 2, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 64, 7>   { enum { WM = 2, WN = 4, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 64, 11>  { enum { WM = 2, WN = 4, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 2, NTW = 4 }; };
-#endif
 template <int C, int K> struct Block3Cfg<ElemBF16, C, K> : Block3Cfg<ElemF16, C, K> {};
 template <> struct Block3Cfg<ElemF32, 32, 3>   { enum { WM = 1, WN = 8, NTW = 2 }; };
 template <> struct Block3Cfg<ElemF32, 32, 7>   { enum { WM = 1, WN = 8, NTW = 2 }; };
@@ -263,10 +256,11 @@ hipError_t pm_launch_mrf(int C, const Block3Args (&blocks)[3], hipStream_t s) {
             if (blocks[j].dil[i] < 1 || blocks[j].dil[i] > 5)
                 return hipErrorNotSupported;
     }
-    switch (C) {
-        case 64: return launch_mrf_c<ET, 64>(blocks, s);
-        case 32: return launch_mrf_c<ET, 32>(blocks, s);
-    }
+    // C = 64 has no registers left for the sum (trunk + accumulator are 128
+    // VGPRs): its whole-MRF variant read-modify-writes `out` through L2, the
+    // lines do not survive there (rocprof: 2.6 GB written per launch instead
+    // of 0.9) and it only ties with three Block launches - not used.
+    if (C == 32) return launch_mrf_c<ET, 32>(blocks, s);
     return hipErrorNotSupported;
 }
 
