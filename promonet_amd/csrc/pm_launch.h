@@ -51,7 +51,9 @@ template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 
 // bytes per MFMA is what buys clock (measured -7 % on k 7 / k 11).
 template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 6, CH = 64, ALIAS = 1, LW = 0 }; };
 #endif
-#ifdef PM_C128_WIDE   // A/B: 384-column tiles
+#ifdef PM_C128_FAT    // A/B: 4 waves (one per SIMD, 512 VGPRs), 64 x 128 wave tiles
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 2, WN = 2, NTW = 4, CH = 64, ALIAS = 0, LW = 0 }; };
+#elif defined(PM_C128_WIDE)   // A/B: 384-column tiles
 template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 6, CH = 32, ALIAS = 1, LW = 0 }; };
 #elif defined(PM_C128_SMALL)   // A/B: half-size workgroups, two per CU
 template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 1, NTW = 4, CH = 64, ALIAS = 1, LW = 0 }; };
