@@ -71,7 +71,10 @@ __global__ __launch_bounds__(512) void kern(
     half8 afirst[G][1];
     load_a_group<ET, 1, G>(afirst, wp, W_MT_STRIDE);
     const char* bptr = smem + (wn * NTW * 32 + ln) * S + lh * 16;
-    if (mode == 1 && wn == 1) valu_phase(acc, scratch, lane, wave, valu_iters);
+    // which waves start in the other phase: the SIMD of a wave is not
+    // documented, so try every pairing (mode 1: w >= 4, 4: odd w, 5: w & 2)
+    const bool shifted = mode == 1 ? wn == 1 : mode == 4 ? (wave & 1) : mode == 5 ? (wave & 2) != 0 : false;
+    if (shifted) valu_phase(acc, scratch, lane, wave, valu_iters);
 #pragma unroll 1
     for (int r = 0; r < reps; ++r) {
 #pragma unroll 1
@@ -105,9 +108,9 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const char* names[4] = {"lock-step phases", "anti-phase, no barriers", "mma only", "valu only"};
-    for (int valu_iters : {16, -48, -96}) {
-        for (int mode = 0; mode < 4; ++mode) {
+    const char* names[6] = {"lock-step phases", "anti-phase (waves 4-7)", "mma only", "valu only", "anti-phase (odd waves)", "anti-phase (waves w&2)"};
+    for (int valu_iters : {-48}) {
+        for (int mode = 0; mode < 6; ++mode) {
             float ms = 0;
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
