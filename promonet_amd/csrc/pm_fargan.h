@@ -288,56 +288,60 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
 // layer, so each streams 1/8 of the weights; the dispatcher places block b on
 // XCD b % 8 and g = b % 8, so each XCD's 4 MB L2 keeps exactly its 1.15 MB
 // slice resident for ALL clusters. After every layer the 8 slices of the
-// output vector are exchanged through a per-cluster global buffer:
-//   publish: write-through (sc1 = relaxed agent-scope atomic) stores, every
-//            storing wave drains vmcnt, barrier, ONE lane adds to the arrival
-//            counter (guide G16 recipe R1 - no fences);
-//   consume: one lane polls the counter relaxed (+ s_sleep) until the epoch's
-//            8 arrivals are in, barrier, sc1 loads (bypass the stale L1).
-// Placement-independent (correct for any block -> XCD map), two payload
-// buffers alternate by epoch parity, counters are zeroed by a memset node
-// before every launch, every spin is bounded and trips a global error word.
+// output vector are exchanged through a per-cluster global buffer of 8-byte
+// {value, epoch} granules (the guide's tagged-granule hand-off):
+//   publish: one relaxed agent-scope 64-bit atomic store per element
+//            (write-through, `sc1`) - value and tag land together;
+//   consume: every thread polls ITS granule (relaxed `sc1` 64-bit load,
+//            s_sleep between tries) until the tag equals the epoch.
+// One L2 round trip per layer; no arrival counter, no vmcnt drain, no barrier
+// before the poll. Placement-independent (correct for any block -> XCD map),
+// two payload buffers alternate by epoch parity (a member can only write
+// epoch e after it has read every member's epoch e - 1, i.e. after every
+// member finished reading epoch e - 2 out of the same buffer), state is zeroed
+// by a memset node before every launch (tag 0 never matches: epochs start at
+// 1), every spin is bounded and trips a global error word.
 // All other state (GRU states, sample history) is replicated per workgroup.
 // ===========================================================================
 #define FG_G 8
 
 struct FgCluster {
-    unsigned* buf;        // [2][768] payload (float bits), this cluster
-    unsigned* counter;    // arrivals, monotonically increasing
-    unsigned* error;      // global: set when a bounded spin gave up
-    unsigned epoch;
+    unsigned long long* buf;   // [2][768] {value bits, epoch} granules
+    unsigned* error;           // global: set when a bounded spin gave up
+    unsigned epoch;            // epochs count from 1
 };
 
 #define FG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // `mine` (valid for tid < nmine) = element r0 + tid of a `total`-long vector;
 // on return dst[0..total) holds the whole vector in every member's LDS.
+// Callers guarantee (barrier at the end of fg_slice) that nobody still reads
+// dst's previous content.
 __device__ __forceinline__ void fg_exchange(
     FgCluster& c, float mine, int r0, int nmine, float* dst, int total,
     int tid) {
-    unsigned* buf = c.buf + (c.epoch & 1u) * 768u;
+    c.epoch += 1u;
+    const unsigned epoch = c.epoch;
+    unsigned long long* buf = c.buf + (epoch & 1u) * 768u;
     if (tid < nmine)
-        __hip_atomic_store(buf + r0 + tid, __float_as_uint(mine), FG_RLX);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(c.counter, 1u, FG_RLX);
-        const unsigned target = FG_G * (c.epoch + 1u);
+        __hip_atomic_store(
+            buf + r0 + tid,
+            ((unsigned long long)epoch << 32) | __float_as_uint(mine), FG_RLX);
+    if (tid < total) {
+        unsigned long long v = __hip_atomic_load(buf + tid, FG_RLX);
         unsigned spins = 0;
-        while (__hip_atomic_load(c.counter, FG_RLX) < target) {
+        while ((unsigned)(v >> 32) != epoch) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0u &&
-                (spins > (1u << 24) || __hip_atomic_load(c.error, FG_RLX))) {
+                (spins > (1u << 22) || __hip_atomic_load(c.error, FG_RLX))) {
                 __hip_atomic_store(c.error, 1u, FG_RLX);
                 break;
             }
+            v = __hip_atomic_load(buf + tid, FG_RLX);
         }
+        dst[tid] = __uint_as_float((unsigned)v);
     }
     __syncthreads();
-    if (tid < total)
-        dst[tid] = __uint_as_float(__hip_atomic_load(buf + tid, FG_RLX));
-    __syncthreads();
-    c.epoch += 1u;
 }
 
 // This member's RW rows (r0 .. r0 + RW) of y = W x: every thread takes one
@@ -377,12 +381,12 @@ __device__ __forceinline__ float fg_slice(
 
 struct FarganClusterArgs {
     FarganArgs f;
-    unsigned* state;      // per cluster: [2 * 768 payload | counter | pad]
+    unsigned* state;      // per cluster: [2][768] 8-byte granules (+ pad)
     unsigned* error;
     int nclusters;
 };
 
-#define FG_CSTATE (2 * 768 + 16)   // uint32 words of cluster state
+#define FG_CSTATE (2 * 768 * 2 + 16)   // uint32 words of cluster state
 
 template <class WT>
 __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
@@ -409,8 +413,8 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
     const int T = a.T;
     const int nin = a.nfeat + a.G;
     FgCluster c;
-    c.buf = ca.state + (size_t)cluster * FG_CSTATE;
-    c.counter = c.buf + 2 * 768;
+    c.buf = reinterpret_cast<unsigned long long*>(
+        ca.state + (size_t)cluster * FG_CSTATE);
     c.error = ca.error;
     c.epoch = 0;
 
