@@ -71,9 +71,20 @@ template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 
 template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1, CH = 64, ALIAS = 0, LW = 0 }; };
 template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0, LW = 0 }; };
 
-template <class ET, int C, int K>
-static hipError_t launch_pair_ck(const PairArgs& a0, hipStream_t stream) {
-    typedef PairCfg<ET, C> G;
+// Latency variant: when the wide tiling yields fewer workgroups than the chip
+// has CUs (single utterances: 8 tiles at C = 256 for 2 s of audio), 64-column
+// (C = 256) / 128-column (C = 128) tiles put 3x / 2x as many CUs to work on a
+// third / half of the per-tile critical path. More halo recompute and weight
+// traffic per column, so only below PM_NARROW_BELOW workgroups.
+template <class ET, int C> struct PairCfgNarrow : PairCfg<ET, C> {};
+template <> struct PairCfgNarrow<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 2, CH = 64, ALIAS = 1, LW = 0 }; };
+template <> struct PairCfgNarrow<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2, CH = 64, ALIAS = 0, LW = 0 }; };
+template <> struct PairCfgNarrow<ElemBF16, 256> : PairCfgNarrow<ElemF16, 256> {};
+template <> struct PairCfgNarrow<ElemBF16, 128> : PairCfgNarrow<ElemF16, 128> {};
+#define PM_NARROW_BELOW 224
+
+template <class ET, int C, int K, class G>
+static hipError_t launch_pair_cfg(const PairArgs& a0, hipStream_t stream) {
     constexpr int WM = G::WM, WN = G::WN, NTW = G::NTW, CH = G::CH;
     constexpr int ALIAS = G::ALIAS, LW = G::LW;
     constexpr int TL = WN * NTW * 32 - (K - 1);
@@ -94,6 +105,19 @@ static hipError_t launch_pair_ck(const PairArgs& a0, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3((WM * WN + LW) * 64), smem,
                        stream, a);
     return hipGetLastError();
+}
+
+template <class ET, int C, int K>
+static hipError_t launch_pair_ck(const PairArgs& a, hipStream_t stream) {
+    typedef PairCfg<ET, C> W;
+    typedef PairCfgNarrow<ET, C> N;
+    if constexpr ((int)N::NTW != (int)W::NTW || (int)N::WN != (int)W::WN) {
+        constexpr int TL = W::WN * W::NTW * 32 - (K - 1);
+        static const bool allowed = !getenv("PM_NO_NARROW");
+        if (allowed && (long long)((a.L + TL - 1) / TL) * a.B < PM_NARROW_BELOW)
+            return launch_pair_cfg<ET, C, K, N>(a, stream);
+    }
+    return launch_pair_cfg<ET, C, K, W>(a, stream);
 }
 
 template <class ET, int C>
@@ -166,9 +190,16 @@ template <> struct Block3Cfg<ElemF32, 64, 3>   { enum { WM = 2, WN = 4, NTW = 2 
 template <> struct Block3Cfg<ElemF32, 64, 7>   { enum { WM = 2, WN = 4, NTW = 2 }; };
 template <> struct Block3Cfg<ElemF32, 64, 11>  { enum { WM = 2, WN = 4, NTW = 2 }; };
 
-template <class ET, int C, int K>
-static hipError_t launch_block3_ck(const Block3Args& a0, hipStream_t stream) {
-    typedef Block3Cfg<ET, C, K> G;
+// Latency variants (see PairCfgNarrow): half the waves, same per-wave tile.
+template <class ET, int C, int K> struct Block3CfgNarrow : Block3Cfg<ET, C, K> {};
+template <> struct Block3CfgNarrow<ElemF16, 32, 11> { enum { WM = 1, WN = 4, NTW = 3 }; };
+template <> struct Block3CfgNarrow<ElemF16, 64, 7>  { enum { WM = 2, WN = 2, NTW = 4 }; };
+template <> struct Block3CfgNarrow<ElemF16, 64, 11> { enum { WM = 2, WN = 2, NTW = 4 }; };
+template <> struct Block3CfgNarrow<ElemF16, 128, 3> { enum { WM = 4, WN = 1, NTW = 4 }; };
+template <int C, int K> struct Block3CfgNarrow<ElemBF16, C, K> : Block3CfgNarrow<ElemF16, C, K> {};
+
+template <class ET, int C, int K, class G>
+static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
     if constexpr (G::WM == 0) {
         return hipErrorNotSupported;
     } else {
@@ -196,6 +227,23 @@ static hipError_t launch_block3_ck(const Block3Args& a0, hipStream_t stream) {
     }
 }
 
+template <class ET, int C, int K>
+static hipError_t launch_block3_ck(const Block3Args& a, hipStream_t stream) {
+    typedef Block3Cfg<ET, C, K> W;
+    typedef Block3CfgNarrow<ET, C, K> N;
+    if constexpr ((int)W::WM != 0 && (int)N::WN != (int)W::WN) {
+        int halo = 0;
+        for (int i = 0; i < a.niter; ++i) halo += (a.dil[i] + 1) * ((K - 1) / 2);
+        const int TL = W::WN * W::NTW * 32 - 2 * halo;
+        const int TLn = N::WN * N::NTW * 32 - 2 * halo;
+        static const bool allowed = !getenv("PM_NO_NARROW");
+        if (allowed && TL > 0 && TLn >= 32 &&
+            (long long)((a.L + TL - 1) / TL) * a.B < PM_NARROW_BELOW)
+            return launch_block3_cfg<ET, C, K, N>(a, stream);
+    }
+    return launch_block3_cfg<ET, C, K, W>(a, stream);
+}
+
 template <class ET, int C>
 static hipError_t launch_block3_c(int K, const Block3Args& a, hipStream_t s) {
     switch (K) {
@@ -207,9 +255,8 @@ static hipError_t launch_block3_c(int K, const Block3Args& a, hipStream_t s) {
 }
 
 // Whole-MRF launch: kernel sizes (3, 7, 11), the k = 11 tiling for all three.
-template <class ET, int C>
-static hipError_t launch_mrf_c(const Block3Args (&blocks)[3], hipStream_t stream) {
-    typedef Block3Cfg<ET, C, 11> G;
+template <class ET, int C, class G>
+static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stream) {
     if constexpr (G::WM == 0 || Block3Cfg<ET, C, 3>::WM == 0 ||
                   Block3Cfg<ET, C, 7>::WM == 0) {
         return hipErrorNotSupported;
@@ -247,6 +294,23 @@ static hipError_t launch_mrf_c(const Block3Args (&blocks)[3], hipStream_t stream
                        dim3(WM * WN * 64), smem, stream, m);
     return hipGetLastError();
     }
+}
+
+template <class ET, int C>
+static hipError_t launch_mrf_c(const Block3Args (&blocks)[3], hipStream_t stream) {
+    typedef Block3Cfg<ET, C, 11> W;
+    typedef Block3CfgNarrow<ET, C, 11> N;
+    if constexpr ((int)W::WM != 0 && (int)N::WN != (int)W::WN) {
+        int halo = 0;
+        for (int i = 0; i < blocks[2].niter; ++i) halo += (blocks[2].dil[i] + 1) * 5;
+        const int TL = W::WN * W::NTW * 32 - 2 * halo;
+        const int TLn = N::WN * N::NTW * 32 - 2 * halo;
+        static const bool allowed = !getenv("PM_NO_NARROW");
+        if (allowed && TL > 0 && TLn >= 32 &&
+            (long long)((blocks[0].L + TL - 1) / TL) * blocks[0].B < PM_NARROW_BELOW)
+            return launch_mrf_cfg<ET, C, N>(blocks, stream);
+    }
+    return launch_mrf_cfg<ET, C, W>(blocks, stream);
 }
 
 template <class ET>
