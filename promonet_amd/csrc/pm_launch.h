@@ -81,7 +81,7 @@ template <> struct PairCfgNarrow<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 2,
 template <> struct PairCfgNarrow<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2, CH = 64, ALIAS = 0, LW = 0 }; };
 template <> struct PairCfgNarrow<ElemBF16, 256> : PairCfgNarrow<ElemF16, 256> {};
 template <> struct PairCfgNarrow<ElemBF16, 128> : PairCfgNarrow<ElemF16, 128> {};
-#define PM_NARROW_BELOW 224
+#define PM_NARROW_BELOW 150   // 3x the tiles must still fit ~2 rounds of 256 CUs
 
 template <class ET, int C, int K, class G>
 static hipError_t launch_pair_cfg(const PairArgs& a0, hipStream_t stream) {
