@@ -47,17 +47,30 @@ __global__ __launch_bounds__(256) void pm_dft_basis_kernel(
 }
 
 // linear_to_mel (spectrogram.py:111-133): out[b][m][t] = log(sum_f
-// basis[m][f] spec[b][f][t]) with optional clamp. One thread per (m, t).
+// basis[m][f] spec[b][f][t]) with optional clamp. One thread per (m, t). A mel
+// filter is a triangle over a few dozen of the F bins: the workgroup first
+// finds its row's non-zero span and sums only that (same order, the skipped
+// terms are exact zeros), so the spectrogram is read ~2x instead of M times.
 __global__ __launch_bounds__(256) void pm_mel_kernel(
     const float* __restrict__ spec, const float* __restrict__ basis,
     float* __restrict__ out, int F, int M, int T, int use_thr, float thr) {
+    __shared__ int span[2];
     const int b = blockIdx.z, m = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
+    const float* br = basis + (size_t)m * F;
+    if (threadIdx.x == 0) { span[0] = F; span[1] = 0; }
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += 256)
+        if (br[f] != 0.f) {
+            atomicMin(&span[0], f);
+            atomicMax(&span[1], f + 1);
+        }
+    __syncthreads();
     if (t >= T) return;
     const float* sp = spec + (size_t)b * F * T + t;
-    const float* br = basis + (size_t)m * F;
     float acc = 0.f;
-    for (int f = 0; f < F; ++f) acc = fmaf(br[f], sp[(size_t)f * T], acc);
+    for (int f = span[0]; f < span[1]; ++f)
+        acc = fmaf(br[f], sp[(size_t)f * T], acc);
     float v = logf(acc);
     if (use_thr) v = fmaxf(v, thr);
     out[((size_t)b * M + m) * T + t] = v;

@@ -1,0 +1,69 @@
+"""Throughput of the preprocessing kernels (GPU box): magnitude spectrogram,
+log-mel and A-weighted 8-band loudness of a batch of 32 x 10 s waveforms, with
+the CPU port (oracle/restatement.py) timed beside them on a bounded sample."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'oracle'))
+import promonet_amd  # noqa: E402
+import restatement as oracle  # noqa: E402
+
+device = torch.device('cuda:0')
+batch, seconds = 32, 10
+samples = promonet_amd.convert.seconds_to_frames(seconds) * promonet_amd.HOPSIZE
+torch.manual_seed(0)
+audio = (torch.rand(batch, 1, samples) * 2 - 1) * .5
+audio_gpu = audio.to(device)
+
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - start) / reps
+
+
+result = {}
+cases = {
+    'spectrogram': lambda: promonet_amd.preprocess.spectrogram.from_audio(audio_gpu),
+    'log_mel': lambda: promonet_amd.preprocess.spectrogram.from_audio(audio_gpu, True),
+    'loudness_8_bands': lambda: promonet_amd.preprocess.loudness.from_audio(audio_gpu[:, 0], 8),
+}
+frames = samples // promonet_amd.HOPSIZE
+bins = promonet_amd.NUM_FFT // 2 + 1
+dft_flops = 2. * promonet_amd.NUM_FFT * 2 * bins * batch * frames
+with torch.inference_mode():
+    for name, fn in cases.items():
+        seconds_per = timed(fn)
+        result[name] = {
+            'ms': seconds_per * 1e3,
+            'audio_seconds_per_second': batch * seconds / seconds_per,
+            'dft_tflops': dft_flops / seconds_per / 1e12}
+    # CPU port on 2 utterances
+    cpu_audio = audio[:2]
+    cpu = {}
+    cpu_cases = {
+        'spectrogram': lambda: oracle.spectrogram(cpu_audio),
+        'loudness_8_bands': lambda: [oracle.loudness(a, 8) for a in cpu_audio],
+    }
+    for name, fn in cpu_cases.items():
+        fn()
+        start = time.perf_counter()
+        fn()
+        cpu[name] = {'ms_for_2_utterances': (time.perf_counter() - start) * 1e3}
+        cpu[name]['audio_seconds_per_second'] = \
+            2 * seconds / (cpu[name]['ms_for_2_utterances'] * 1e-3)
+    result['cpu_port'] = cpu
+for key, value in result.items():
+    print(key, value)
+print(json.dumps(result))
