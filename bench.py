@@ -35,6 +35,10 @@ FLOP_PER_SAMPLE = 2_399_772          # conv + convT MACs x 2
 ELEMENTS_PER_SAMPLE = 5_101.4        # layer-granular activation elements
 PEAK_TFLOPS = {'f16': 2500., 'bf16': 2500., 'fp32': 157.3}   # dense MFMA
 PEAK_HBM_GBS = 8000.
+# sustained register-resident MFMA rate on random operands under the power cap
+# (scripts/micro/mfma_peak.hip, profiles/r01/micro_mfma.txt): what an MFMA
+# kernel can reach on this part; reported beside the nominal peak
+SUSTAINED_TFLOPS = {'f16': 1650., 'bf16': 1650.}
 
 
 def parse_args():
@@ -246,6 +250,10 @@ def main():
                 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_TFLOPS[args.dtype],
                 'traffic': traffic,
+                'sustained_peak': SUSTAINED_TFLOPS.get(args.dtype),
+                'frac_of_sustained_peak': (
+                    achieved / SUSTAINED_TFLOPS[args.dtype]
+                    if args.dtype in SUSTAINED_TFLOPS else None),
                 'avg_launch_ms': avg_ms,
                 'launches_per_step': row['launches'] // args.steps,
                 'algorithmic_flops_per_launch': flops_per_launch,
