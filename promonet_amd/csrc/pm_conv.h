@@ -246,9 +246,8 @@ __host__ __device__ constexpr int pair_smem_bytes(int d) {
     return ALIAS ? (x > inter ? x : inter) : x + inter;
 }
 
-template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS,
-          int LW>
-__global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
+template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS>
+__global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     PairArgs a) {
     typedef typename ET::frag_t frag_t;
     constexpr int NCH = C / CH;
@@ -257,8 +256,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
     constexpr int MTW = MT / WM;
     static_assert(MT % WM == 0, "WM must divide the M tile count");
     constexpr int N1 = WN * NTW * 32;
-    constexpr int NT = WM * WN * 64;           // MFMA (consumer) threads
-    constexpr int NTS = LW ? LW * 64 : NT;     // threads that stage x chunks
+    constexpr int NT = WM * WN * 64;
     constexpr int H2 = (K - 1) / 2;
     constexpr int TL = N1 - (K - 1);
     constexpr int SX = CH * ET::ESZ + 16;
@@ -295,10 +293,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
 
     floatx16 acc[MTW][NTW];
     floatx16 bv[MTW];
-    if (LW == 0 || wave < WM * WN) {
-        load_bias_vec<MTW>(bv, a.b1, wm * MTW * 32 + 4 * lh);
-        init_acc<MTW, NTW>(acc, bv);
-    }
+    load_bias_vec<MTW>(bv, a.b1, wm * MTW * 32 + 4 * lh);
+    init_acc<MTW, NTW>(acc, bv);
 
     // ---------------- conv1: K-loop over staged channel chunks -------------
     const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1) +
@@ -312,48 +308,6 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
         ((wn * NTW * 32) + ln) * SX + lh * 8 * ET::ESZ;
     frag_t afirst[G][MTW];
 
-    if constexpr (LW > 0) {
-        // ---- producer / consumer split --------------------------------
-        // vmcnt retires loads IN ORDER: a wave with the next chunk's
-        // HBM-latency activation loads in flight stalls at its very next
-        // L2 weight-fragment wait. LW extra loader waves own the staging
-        // (load fp32 -> lrelu -> f16 -> LDS); the MFMA waves only ever have
-        // weight loads in flight. Both meet at the per-chunk barrier.
-        if (wave >= WM * WN) {
-            const int ltid = tid - NT;
-            ChunkStager<ET, CH, NTS, XR_MAX> stager;
-            stager.load(xb, C, 0, t_first, XR, L, ltid);
-            stager.template store<true>(xbuf, XR, ltid);
-            __syncthreads();
-#pragma unroll 1
-            for (int c = 0; c + 1 < NCH; ++c) {
-                stager.load(xb, C, (c + 1) * CH, t_first, XR, L, ltid);
-                stager.template store<true>(
-                    xbuf + ((c + 1) & 1) * XR * SX, XR, ltid);
-                __syncthreads();
-            }
-            if (ALIAS) __syncthreads();
-            __syncthreads();          // epilogue-1 barrier of the consumers
-            return;
-        }
-        load_a_group<ET, MTW, G>(afirst, w1, W_MT_STRIDE);
-        __syncthreads();
-        PM_STAMP(a, 1);
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            char* cur = xbuf + (NCH > 1 ? (c & 1) * XR * SX : 0);
-            const bool more = c + 1 < NCH;
-            mma_taps<ET, K, KC, MTW, NTW, G, SX>(
-                acc, cur + lane_off_x, d * SX, w1 + (size_t)c * W_CHUNK,
-                W_MT_STRIDE, afirst,
-                more ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
-            if (c < 2) PM_STAMP(a, 6 + 3 * c);
-            if (more) {
-                __syncthreads();
-                if (c < 2) PM_STAMP(a, 8 + 3 * c);
-            }
-        }
-    } else {
     load_a_group<ET, MTW, G>(afirst, w1, W_MT_STRIDE);
 
     ChunkStager<ET, CH, NT, XR_MAX> stager;
@@ -380,7 +334,6 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_pair_kernel(
             __syncthreads();
             if (c < 2) PM_STAMP(a, 8 + 3 * c);
         }
-    }
     }
 
     PM_STAMP(a, 2);

@@ -41,35 +41,22 @@ template <class ET, int C> struct PairCfg;
 // (LDS 160,480 B at k 11, d 5).
 // CH: input channels staged per LDS chunk (one barrier per chunk). Measured:
 // CH = 128 (half the barriers, LDS tiles aliased) is 4 % slower than 64.
-#ifdef PM_C256_NARROW   // A/B: the previous 128-column tiles
-template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 64, ALIAS = 0, LW = 0 }; };
-#elif defined(PM_LOADER_WAVES)   // A/B: 4 extra waves own the activation staging
-template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 4, CH = 64, ALIAS = 0, LW = 4 }; };
-#else
 // 192 columns per weight fetch (LDS tiles aliased to fit): the pair kernels
 // run at the power wall with the L2 94 % busy streaming weights, so fewer L2
 // bytes per MFMA is what buys clock (measured -7 % on k 7 / k 11).
-template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 6, CH = 64, ALIAS = 1, LW = 0 }; };
-#endif
-#ifdef PM_C128_FAT    // A/B: 4 waves (one per SIMD, 512 VGPRs), 64 x 128 wave tiles
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 2, WN = 2, NTW = 4, CH = 64, ALIAS = 0, LW = 0 }; };
-#elif defined(PM_C128_WIDE)   // A/B: 384-column tiles
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 6, CH = 32, ALIAS = 1, LW = 0 }; };
-#elif defined(PM_C128_SMALL)   // A/B: half-size workgroups, two per CU
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 1, NTW = 4, CH = 64, ALIAS = 1, LW = 0 }; };
-#elif defined(PM_LOADER_WAVES)
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0, LW = 4 }; };
-#else
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0, LW = 0 }; };
-#endif
-template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2, CH = 64, ALIAS = 0, LW = 0 }; };
-template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0, LW = 0 }; };
+template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 6, CH = 64, ALIAS = 1 }; };
+// C = 128 alternatives measured and dropped: 384-column tiles with CH = 32
+// (neutral), two 4-wave 128-column workgroups per CU (neutral: L2 weight
+// traffic doubles), one fat wave per SIMD with 64 x 128 tiles (+1...+4 %).
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
 template <int C> struct PairCfg<ElemBF16, C> : PairCfg<ElemF16, C> {};
 // exact fp32 operands: LDS rows are twice as wide -> 64-column tiles
-template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0, LW = 0 }; };
-template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0, LW = 0 }; };
-template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1, CH = 64, ALIAS = 0, LW = 0 }; };
-template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0, LW = 0 }; };
+template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
 
 // Latency variant: when the wide tiling yields fewer workgroups than the chip
 // has CUs (single utterances: 8 tiles at C = 256 for 2 s of audio), 64-column
@@ -77,8 +64,8 @@ template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 
 // third / half of the per-tile critical path. More halo recompute and weight
 // traffic per column, so only below PM_NARROW_BELOW workgroups.
 template <class ET, int C> struct PairCfgNarrow : PairCfg<ET, C> {};
-template <> struct PairCfgNarrow<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 2, CH = 64, ALIAS = 1, LW = 0 }; };
-template <> struct PairCfgNarrow<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2, CH = 64, ALIAS = 0, LW = 0 }; };
+template <> struct PairCfgNarrow<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 2, CH = 64, ALIAS = 1 }; };
+template <> struct PairCfgNarrow<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2, CH = 64, ALIAS = 0 }; };
 template <> struct PairCfgNarrow<ElemBF16, 256> : PairCfgNarrow<ElemF16, 256> {};
 template <> struct PairCfgNarrow<ElemBF16, 128> : PairCfgNarrow<ElemF16, 128> {};
 #define PM_NARROW_BELOW 150   // 3x the tiles must still fit ~2 rounds of 256 CUs
@@ -86,11 +73,11 @@ template <> struct PairCfgNarrow<ElemBF16, 128> : PairCfgNarrow<ElemF16, 128> {}
 template <class ET, int C, int K, class G>
 static hipError_t launch_pair_cfg(const PairArgs& a0, hipStream_t stream) {
     constexpr int WM = G::WM, WN = G::WN, NTW = G::NTW, CH = G::CH;
-    constexpr int ALIAS = G::ALIAS, LW = G::LW;
+    constexpr int ALIAS = G::ALIAS;
     constexpr int TL = WN * NTW * 32 - (K - 1);
     PairArgs a = a0;
     a.ntiles = (a.L + TL - 1) / TL;
-    auto kern = conv_pair_kernel<ET, C, K, WM, WN, NTW, CH, ALIAS, LW>;
+    auto kern = conv_pair_kernel<ET, C, K, WM, WN, NTW, CH, ALIAS>;
     const int smem =
         pair_smem_bytes<ET, C, K, WM, WN, NTW, CH, ALIAS>(a.dilation);
     static int max_set = 0;
@@ -102,7 +89,7 @@ static hipError_t launch_pair_cfg(const PairArgs& a0, hipStream_t stream) {
         max_set = smem;
     }
     const int grid = a.ntiles * a.B;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3((WM * WN + LW) * 64), smem,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem,
                        stream, a);
     return hipGetLastError();
 }
