@@ -216,7 +216,8 @@ def main():
                 f'{label}:{args.dtype}')
         kernel_ms = sum(r['ms'] for r in profile.values()) / args.steps
         result = {
-            'metric': 'audio samples/sec (22.05 kHz), batch-32 10 s utterances',
+            'metric': f'audio samples/sec (22.05 kHz), batch-{args.batch} '
+                      f'{args.seconds:g} s utterances',
             'value': value,
             'unit': 'samples/s',
             'n_gpus': world,
