@@ -875,10 +875,13 @@ extern "C" int pm_prepare_features(
     a.fmin = fmin; a.fmax = fmax; a.min_db = min_db;
     a.db_range = ref_db - min_db;
     a.period_rate = period_rate;
-    constexpr int TH = 128;
-    hipLaunchKernelGGL(pm_prepare_features_kernel<TH>,
-                       dim3((T + TH - 1) / TH, B), dim3(TH),
-                       (size_t)P * TH * sizeof(float), (hipStream_t)stream, a);
+    constexpr int FR = 64;     // frames per workgroup
+    const int width = a.Cpad > C ? a.Cpad : C;
+    const size_t smem = ((size_t)P * FR + (size_t)FR * (width + 1) + 6 * FR) *
+                        sizeof(float);
+    hipLaunchKernelGGL(pm_prepare_features_kernel<FR>,
+                       dim3((T + FR - 1) / FR, B), dim3(256), smem,
+                       (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return PM_OK;
 }

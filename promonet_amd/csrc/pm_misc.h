@@ -112,7 +112,6 @@ __global__ __launch_bounds__(256) void pm_to_channels_last_kernel(
 
 // ---------------------------------------------------------------------------
 // Generator.prepare_features  (model/generator.py:137-197, default config)
-// One thread per frame; the frame's PPG column lives in LDS.
 //   channels [ppg 0:40 | pitch embedding 40:104 | loudness 104:112 | per 112]
 // ---------------------------------------------------------------------------
 struct FeatureArgs {
@@ -132,97 +131,133 @@ struct FeatureArgs {
     float period_rate;         // > 0: append SAMPLE_RATE / hz (FARGAN)
 };
 
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void pm_prepare_features_kernel(
+// A workgroup of 256 threads builds the rows of FRAMES = 64 consecutive frames
+// in LDS - work items are (frame, channel) pairs, so every global read is
+// coalesced along time and the 40 x 40 rank comparisons of a frame are spread
+// over 40 threads - and writes them out as one contiguous (64, Cpad) block of
+// the channels-last tensor (and / or channel rows of the reference layout).
+// Arithmetic per value is unchanged: rank by counting with index tie-break,
+// torch's lerp, log / max / exp / sequential sum in channel order.
+template <int FRAMES>
+__global__ __launch_bounds__(256) void pm_prepare_features_kernel(
     FeatureArgs a) {
-    extern __shared__ float col[];  // [P][THREADS]
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * THREADS + threadIdx.x;
-    const int tx = threadIdx.x;
-    const int T = a.T, P = a.P;
-    if (t >= T) return;
+    constexpr int NT = 256;
+    extern __shared__ float sm[];
+    const int P = a.P, T = a.T;
     const int Cb = P + a.E + a.bands + 1;
     const int C = Cb + (a.period_rate > 0.f ? 1 : 0);
-    float* ocl = a.out_cl ? a.out_cl + ((size_t)b * T + t) * a.Cpad : nullptr;
-    float* oref = a.out_ref ? a.out_ref + (size_t)b * C * T + t : nullptr;
+    const int W = a.Cpad > C ? a.Cpad : C;     // row width (Cpad is 0 without out_cl)
+    const int RS = W + 1;                      // row stride (odd: no conflicts)
+    float* col = sm;                           // [P][FRAMES] raw ppg
+    float* row = col + P * FRAMES;             // [FRAMES][RS] assembled rows
+    float* quant = row + FRAMES * RS;          // [2][FRAMES] below / above
+    float* stat = quant + 2 * FRAMES;          // [2][FRAMES] max, sum
+    float* hzs = stat + 2 * FRAMES;            // [FRAMES] clipped pitch
+    int* bins = reinterpret_cast<int*>(hzs + FRAMES);   // [FRAMES]
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * FRAMES;
+    const int nf = min(FRAMES, T - t0);        // live frames of this tile
+    const int tid = threadIdx.x;
+
+    // ppg tile, pitch, zero the padded tail of every row
+    for (int i = tid; i < P * FRAMES; i += NT) {
+        const int c = i / FRAMES, f = i % FRAMES;
+        col[i] = f < nf ? a.ppg[((size_t)b * P + c) * T + t0 + f] : 0.f;
+    }
+    for (int i = tid; i < FRAMES * (W - C); i += NT) {
+        const int f = i / (W - C), c = C + i % (W - C);
+        row[f * RS + c] = 0.f;
+    }
+    if (tid < FRAMES) {
+        // --- pitch: clip, searchsorted(right=False), clip (:152-164) ---
+        float hz = tid < nf ? a.pitch[(size_t)b * T + t0 + tid] : a.fmin;
+        hz = fminf(fmaxf(hz, a.fmin), a.fmax);
+        int lo = 0, hi = a.NB;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (a.pitch_edges[mid] < hz) lo = mid + 1; else hi = mid;
+        }
+        hzs[tid] = hz;
+        bins[tid] = lo > a.NB - 1 ? a.NB - 1 : lo;
+    }
+    __syncthreads();
 
     // --- ppgs.sparsify(ppg, 'percentile', 0.85)  (generator.py:140-147) ---
-    const float* pp = a.ppg + (size_t)b * P * T + t;
-    for (int i = 0; i < P; ++i) col[i * THREADS + tx] = pp[(size_t)i * T];
-    float below = 0.f, above = 0.f;
-    for (int i = 0; i < P; ++i) {
-        const float vi = col[i * THREADS + tx];
+    for (int i = tid; i < P * FRAMES; i += NT) {
+        const int c = i / FRAMES, f = i % FRAMES;
+        const float vi = col[i];
         int rank = 0;
         for (int j = 0; j < P; ++j) {
-            const float vj = col[j * THREADS + tx];
-            rank += (vj < vi) || (vj == vi && j < i);
+            const float vj = col[j * FRAMES + f];
+            rank += (vj < vi) || (vj == vi && j < c);
         }
-        if (rank == a.rank_below) below = vi;
-        if (rank == a.rank_above) above = vi;
+        if (rank == a.rank_below) quant[f] = vi;
+        if (rank == a.rank_above) quant[FRAMES + f] = vi;
     }
-    // torch lerp (weight < 0.5 branch is the one 0.85 * 39 takes)
-    const float wq = a.rank_weight;
-    const float q = wq < 0.5f ? below + wq * (above - below)
-                              : above - (above - below) * (1.f - wq);
-    float mx = -INFINITY;
-    for (int i = 0; i < P; ++i) {
-        float v = col[i * THREADS + tx];
-        v = v > q ? v : 0.f;
-        v = logf(v + 1e-8f);
-        col[i * THREADS + tx] = v;
-        mx = fmaxf(mx, v);
+    __syncthreads();
+    if (tid < FRAMES) {
+        const int f = tid;
+        const float below = quant[f], above = quant[FRAMES + f];
+        // torch lerp (weight < 0.5 branch is the one 0.85 * 39 takes)
+        const float wq = a.rank_weight;
+        const float q = wq < 0.5f ? below + wq * (above - below)
+                                  : above - (above - below) * (1.f - wq);
+        float mx = -INFINITY;
+        for (int c = 0; c < P; ++c) {
+            float v = col[c * FRAMES + f];
+            v = v > q ? v : 0.f;
+            v = logf(v + 1e-8f);
+            col[c * FRAMES + f] = v;
+            mx = fmaxf(mx, v);
+        }
+        float sum = 0.f;
+        for (int c = 0; c < P; ++c) {
+            const float ev = expf(col[c * FRAMES + f] - mx);
+            col[c * FRAMES + f] = ev;
+            sum += ev;
+        }
+        stat[f] = sum;
+        // periodicity (:187-188), FARGAN pitch period (:191-195)
+        row[f * RS + Cb - 1] =
+            f < nf ? a.periodicity[(size_t)b * T + t0 + f] : 0.f;
+        if (C > Cb) row[f * RS + Cb] = a.period_rate / hzs[f];
     }
-    float sum = 0.f;
-    for (int i = 0; i < P; ++i) {
-        const float ev = expf(col[i * THREADS + tx] - mx);
-        col[i * THREADS + tx] = ev;
-        sum += ev;
+    __syncthreads();
+    for (int i = tid; i < P * FRAMES; i += NT) {
+        const int c = i / FRAMES, f = i % FRAMES;
+        row[f * RS + c] = col[i] / stat[f];
     }
-    for (int i = 0; i < P; ++i) {
-        const float v = col[i * THREADS + tx] / sum;
-        if (ocl) ocl[i] = v;
-        if (oref) oref[(size_t)i * T] = v;
+    // pitch embedding gather (:160-164)
+    for (int i = tid; i < a.E * FRAMES; i += NT) {
+        const int f = i / a.E, e = i % a.E;
+        row[f * RS + P + e] = a.pitch_table[(size_t)bins[f] * a.E + e];
     }
-
-    // --- pitch: clip, searchsorted(right=False), clip, embed (:152-164) ---
-    float hz = a.pitch[(size_t)b * T + t];
-    hz = fminf(fmaxf(hz, a.fmin), a.fmax);
-    int lo = 0, hi = a.NB;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (a.pitch_edges[mid] < hz) lo = mid + 1; else hi = mid;
-    }
-    const int bin = lo > a.NB - 1 ? a.NB - 1 : lo;
-    const float* emb = a.pitch_table + (size_t)bin * a.E;
-    for (int i = 0; i < a.E; ++i) {
-        const float v = emb[i];
-        if (ocl) ocl[P + i] = v;
-        if (oref) oref[(size_t)(P + i) * T] = v;
-    }
-
     // --- loudness band means + normalize (:172-184, loudness.py:144-146) ---
-    const float* lp = a.loudness + (size_t)b * a.F * T + t;
-    for (int band = 0; band < a.bands; ++band) {
-        float s = 0.f;
-        const int r0 = a.band_start[band], r1 = a.band_start[band + 1];
-        for (int r = r0; r < r1; ++r) s += lp[(size_t)r * T];
-        const float v = (s / (float)(r1 - r0) - a.min_db) / a.db_range;
-        if (ocl) ocl[P + a.E + band] = v;
-        if (oref) oref[(size_t)(P + a.E + band) * T] = v;
+    for (int i = tid; i < a.bands * FRAMES; i += NT) {
+        const int band = i / FRAMES, f = i % FRAMES;
+        float v = 0.f;
+        if (f < nf) {
+            const float* lp = a.loudness + (size_t)b * a.F * T + t0 + f;
+            float s = 0.f;
+            const int r0 = a.band_start[band], r1 = a.band_start[band + 1];
+            for (int r = r0; r < r1; ++r) s += lp[(size_t)r * T];
+            v = (s / (float)(r1 - r0) - a.min_db) / a.db_range;
+        }
+        row[f * RS + P + a.E + band] = v;
     }
+    __syncthreads();
 
-    // --- periodicity (:187-188) + zero channel padding ---
-    const float per = a.periodicity[(size_t)b * T + t];
-    // pitch period in samples for the FARGAN lookback (generator.py:191-195)
-    const float period = a.period_rate > 0.f ? a.period_rate / hz : 0.f;
-    if (ocl) {
-        ocl[Cb - 1] = per;
-        if (C > Cb) ocl[Cb] = period;
-        for (int i = C; i < a.Cpad; ++i) ocl[i] = 0.f;
+    if (a.out_cl) {
+        float* o = a.out_cl + ((size_t)b * T + t0) * a.Cpad;
+        for (int i = tid; i < nf * a.Cpad; i += NT)
+            o[i] = row[(i / a.Cpad) * RS + i % a.Cpad];
     }
-    if (oref) {
-        oref[(size_t)(Cb - 1) * T] = per;
-        if (C > Cb) oref[(size_t)Cb * T] = period;
+    if (a.out_ref) {
+        float* o = a.out_ref + (size_t)b * C * T + t0;
+        for (int i = tid; i < C * FRAMES; i += NT) {
+            const int c = i / FRAMES, f = i % FRAMES;
+            if (f < nf) o[(size_t)c * T + f] = row[f * RS + c];
+        }
     }
 }
 
