@@ -1354,10 +1354,12 @@ extern "C" int pm_fargan_finalize(pm_fargan_t h, void* stream) {
     return PM_OK;
 }
 
-// Kernel choice. Measured (MI355X, 10 s utterances): clusters of 8 workgroups
-// take 140 ms per wave of 32 utterances, one workgroup per utterance takes
-// 720 ms per wave of 256 -> clusters win up to ~160 utterances per launch.
-// PM_FARGAN=single|cluster overrides, as does pm_fargan_set_mode().
+// Kernel choice. Measured (MI355X, 10 s utterances, fp32 weights): clusters of
+// 8 workgroups take 112 ms for 32 utterances (one per cluster), 162 ms for 64
+// (two in lockstep per cluster), 242 ms for 128 and 485 ms for 256 (four in
+// lockstep, two waves); one workgroup per utterance takes 721 ms per wave of
+// 256 -> clusters at every batch size. PM_FARGAN=single|cluster overrides, as
+// does pm_fargan_set_mode().
 static bool fargan_use_cluster(pm_fargan_t h, int B) {
     static int forced = -1;
     if (forced < 0) {
@@ -1367,7 +1369,8 @@ static bool fargan_use_cluster(pm_fargan_t h, int B) {
     const int mode = h->mode ? h->mode : forced;
     if (mode == 1) return false;
     if (mode == 2) return true;
-    return B <= 160;
+    (void)B;
+    return true;
 }
 
 extern "C" int pm_fargan_set_mode(pm_fargan_t h, int mode) {
@@ -1406,11 +1409,26 @@ static int fargan_launch(
         ca.f = a;
         ca.state = (unsigned*)cluster_state;
         ca.error = ca.state + (size_t)FG_MAX_CLUSTERS * FG_CSTATE;
-        ca.nclusters = a.B < FG_MAX_CLUSTERS ? a.B : FG_MAX_CLUSTERS;
-        hipLaunchKernelGGL(pm_fargan_cluster_kernel<WT>,
-                           dim3(ca.nclusters * FG_G), dim3(FG_THREADS), 0, s,
-                           ca, w);
-        HIP_TRY(hipGetLastError());
+        // U utterances per cluster in lockstep: 1 up to 32 utterances (one
+        // cluster per utterance fills the 256 CUs), then 2, then 4
+        const int U = a.B <= FG_MAX_CLUSTERS ? 1
+                    : a.B <= 2 * FG_MAX_CLUSTERS ? 2 : FG_UMAX;
+        const int groups = (a.B + U - 1) / U;
+        ca.nclusters = groups < FG_MAX_CLUSTERS ? groups : FG_MAX_CLUSTERS;
+        const dim3 grid(ca.nclusters * FG_G), block(FG_THREADS);
+        const size_t smem = (size_t)U * sizeof(FgLds);
+        auto launch = [&](auto kern) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(kern),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, block, smem, s, ca, w);
+            return hipGetLastError();
+        };
+        hipError_t e = U == 1 ? launch(pm_fargan_cluster_kernel<WT, 1>)
+                     : U == 2 ? launch(pm_fargan_cluster_kernel<WT, 2>)
+                              : launch(pm_fargan_cluster_kernel<WT, FG_UMAX>);
+        HIP_TRY(e);
         return PM_OK;
     }
     hipLaunchKernelGGL(pm_fargan_kernel<WT>, dim3(a.B), dim3(FG_THREADS), 0, s,

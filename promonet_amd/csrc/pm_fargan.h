@@ -13,6 +13,7 @@
 // through LDS. Utterances are independent -> B workgroups run concurrently.
 #pragma once
 #include "pm_common.h"
+#include <cstddef>
 
 #ifndef FG_UNROLL
 #define FG_UNROLL 16
@@ -27,6 +28,15 @@
 template <class WT> struct FgVec;
 template <> struct FgVec<float> {
     static constexpr int VEC = 4;
+    __device__ static __forceinline__ void unpack(uint4 wv, float (&f)[4]) {
+        f[0] = __uint_as_float(wv.x); f[1] = __uint_as_float(wv.y);
+        f[2] = __uint_as_float(wv.z); f[3] = __uint_as_float(wv.w);
+    }
+    __device__ static __forceinline__ float dotf(
+        const float (&f)[4], const float* x) {
+        const float4 b = *reinterpret_cast<const float4*>(x);
+        return f[0] * b.x + f[1] * b.y + f[2] * b.z + f[3] * b.w;
+    }
     __device__ static __forceinline__ float dot(
         const float* __restrict__ w, const float* x) {
         const float4 a = *reinterpret_cast<const float4*>(w);
@@ -36,6 +46,20 @@ template <> struct FgVec<float> {
 };
 template <> struct FgVec<_Float16> {
     static constexpr int VEC = 8;
+    // 16 weight bytes already in registers -> fp32 once, then one dot per
+    // utterance (same product order as dot())
+    __device__ static __forceinline__ void unpack(uint4 wv, float (&f)[8]) {
+        const half8 a = __builtin_bit_cast(half8, wv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)a[i];
+    }
+    __device__ static __forceinline__ float dotf(
+        const float (&f)[8], const float* x) {
+        const float4 b0 = *reinterpret_cast<const float4*>(x);
+        const float4 b1 = *reinterpret_cast<const float4*>(x + 4);
+        return f[0] * b0.x + f[1] * b0.y + f[2] * b0.z + f[3] * b0.w +
+               f[4] * b1.x + f[5] * b1.y + f[6] * b1.z + f[7] * b1.w;
+    }
     __device__ static __forceinline__ float dot(
         const _Float16* __restrict__ w, const float* x) {
         const half8 a = *reinterpret_cast<const half8*>(w);
@@ -305,56 +329,95 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
 // ===========================================================================
 #define FG_G 8
 
+#define FG_UMAX 4              // utterances a cluster advances in lockstep
+
 struct FgCluster {
-    unsigned long long* buf;   // [2][768] {value bits, epoch} granules
+    unsigned long long* buf;   // [2][FG_UMAX][768] {value bits, epoch} granules
     unsigned* error;           // global: set when a bounded spin gave up
     unsigned epoch;            // epochs count from 1
 };
 
 #define FG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-// `mine` (valid for tid < nmine) = element r0 + tid of a `total`-long vector;
-// on return dst[0..total) holds the whole vector in every member's LDS.
-// Callers guarantee (barrier at the end of fg_slice) that nobody still reads
-// dst's previous content.
+// Per-utterance recurrent state + scratch of one cluster member, in LDS.
+struct FgLds {
+    float condin[376];
+    float c1[384];
+    float c2[384];
+    float cond[512];
+    float subin[2 * FG_SUBIN + 8];
+    float skipbuf[FG_SKIP];
+    float hid[3][FG_HOP];
+    float f1[FG_HOP];
+    float prev[FG_PREV];
+    float fresh[FG_SUB];
+    float part[FG_THREADS];
+    float part2[FG_THREADS];
+};
+static_assert(sizeof(FgLds) % 16 == 0, "16-byte aligned per-utterance state");
+#define FG_OFF(field) (offsetof(FgLds, field) / sizeof(float))
+#define FG_LSTRIDE (sizeof(FgLds) / sizeof(float))
+
+// `mine[u]` (valid for tid < nmine) = element r0 + tid of utterance u's
+// `total`-long vector; on return field `dst` of every utterance's FgLds holds
+// the whole vector in every member's LDS. Callers guarantee (barrier at the
+// end of fg_slice) that nobody still reads dst's previous content.
+template <int U>
 __device__ __forceinline__ void fg_exchange(
-    FgCluster& c, float mine, int r0, int nmine, float* dst, int total,
-    int tid) {
+    FgCluster& c, const float (&mine)[U], int r0, int nmine, float* lds,
+    int dst, int total, int tid) {
     c.epoch += 1u;
     const unsigned epoch = c.epoch;
-    unsigned long long* buf = c.buf + (epoch & 1u) * 768u;
-    if (tid < nmine)
-        __hip_atomic_store(
-            buf + r0 + tid,
-            ((unsigned long long)epoch << 32) | __float_as_uint(mine), FG_RLX);
+    unsigned long long* buf = c.buf + (epoch & 1u) * (FG_UMAX * 768u);
+    if (tid < nmine) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            __hip_atomic_store(
+                buf + u * 768 + r0 + tid,
+                ((unsigned long long)epoch << 32) | __float_as_uint(mine[u]),
+                FG_RLX);
+    }
     if (tid < total) {
-        unsigned long long v = __hip_atomic_load(buf + tid, FG_RLX);
+        // the U granules of this thread are polled together: their loads are
+        // independent, so a try costs one round trip, not U
+        unsigned long long v[U];
         unsigned spins = 0;
-        while ((unsigned)(v >> 32) != epoch) {
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                v[u] = __hip_atomic_load(buf + u * 768 + tid, FG_RLX);
+#pragma unroll
+            for (int u = 0; u < U; ++u) all &= (unsigned)(v[u] >> 32) == epoch;
+            if (all) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0u &&
                 (spins > (1u << 22) || __hip_atomic_load(c.error, FG_RLX))) {
                 __hip_atomic_store(c.error, 1u, FG_RLX);
                 break;
             }
-            v = __hip_atomic_load(buf + tid, FG_RLX);
         }
-        dst[tid] = __uint_as_float((unsigned)v);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            lds[u * FG_LSTRIDE + dst + tid] = __uint_as_float((unsigned)v[u]);
     }
     __syncthreads();
 }
 
-// This member's RW rows (r0 .. r0 + RW) of y = W x: every thread takes one
-// (row, K-slice) pair, partial sums meet in LDS. Returns the row's sum in
-// threads tid < RW.
-template <class WT, int RW, int RPAD>
-__device__ __forceinline__ float fg_slice(
-    const WT* __restrict__ w, const float* xa, const float* xb, int split,
-    int kpad, int r0, float* part, int tid) {
+// This member's RW rows (r0 .. r0 + RW) of y_u = W x_u for the U utterances:
+// every thread takes one (row, K-slice) pair, loads each 16-byte weight block
+// ONCE and dots it with the U input vectors (LDS fields xa / xb of every
+// FgLds); partial sums meet in LDS. sum[u] is valid in threads tid < RW.
+template <class WT, int RW, int RPAD, int U>
+__device__ __forceinline__ void fg_slice(
+    const WT* __restrict__ w, const float* lds, int xa, int xb, int split,
+    int kpad, int r0, float* ldsw, int tid, float (&sum)[U]) {
     constexpr int VEC = FgVec<WT>::VEC;
     constexpr int PARTS = FG_THREADS / RW;
     const int row = tid % RW, p = tid / RW;
-    float acc0 = 0.f, acc1 = 0.f;
+    float acc0[U], acc1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc0[u] = acc1[u] = 0.f;
     if (p < PARTS) {
         const int blocks = kpad / VEC;
         const int b0 = p * blocks / PARTS, b1 = (p + 1) * blocks / PARTS;
@@ -362,50 +425,55 @@ __device__ __forceinline__ float fg_slice(
         const WT* wp = w + ((size_t)b0 * RPAD + r0 + row) * VEC;
 #pragma unroll 4
         for (int b = b0; b < b1; ++b) {
-            const float* x = b < sb ? xa + b * VEC : xb + (b - sb) * VEC;
-            const float d = FgVec<WT>::dot(wp, x);
-            if (b & 1) acc1 += d; else acc0 += d;
+            float wf[VEC];
+            FgVec<WT>::unpack(*reinterpret_cast<const uint4*>(wp), wf);
+            const int off = b < sb ? xa + b * VEC : xb + (b - sb) * VEC;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float d = FgVec<WT>::dotf(wf, lds + u * FG_LSTRIDE + off);
+                if (b & 1) acc1[u] += d; else acc0[u] += d;
+            }
             wp += (size_t)RPAD * VEC;
         }
     }
-    part[tid] = acc0 + acc1;
-    __syncthreads();
-    float sum = 0.f;
-    if (tid < RW) {
 #pragma unroll
-        for (int q = 0; q < PARTS; ++q) sum += part[tid + q * RW];
+    for (int u = 0; u < U; ++u)
+        ldsw[u * FG_LSTRIDE + FG_OFF(part) + tid] = acc0[u] + acc1[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float t = 0.f;
+        if (tid < RW) {
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q)
+                t += lds[u * FG_LSTRIDE + FG_OFF(part) + tid + q * RW];
+        }
+        sum[u] = t;
     }
     __syncthreads();
-    return sum;
 }
 
 struct FarganClusterArgs {
     FarganArgs f;
-    unsigned* state;      // per cluster: [2][768] 8-byte granules (+ pad)
+    unsigned* state;      // per cluster: [2][FG_UMAX][768] granules (+ pad)
     unsigned* error;
     int nclusters;
 };
 
-#define FG_CSTATE (2 * 768 * 2 + 16)   // uint32 words of cluster state
+#define FG_CSTATE (2 * FG_UMAX * 768 * 2 + 16)   // uint32 words per cluster
 
-template <class WT>
+// U utterances per cluster advance in lockstep: the weight slice is read once
+// per layer for all of them and one exchange carries U vectors, so the
+// latency of a layer (an L2-and-beyond round trip) is shared U ways. U = 1 is
+// the batch <= 32 case (one utterance per cluster, 32 clusters = 256 CUs).
+template <class WT, int U>
 __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
     FarganClusterArgs ca, FarganWeights<WT> w) {
     const FarganArgs& a = ca.f;
     constexpr int NT = FG_THREADS;
     constexpr int CPAD = 376;
-    __shared__ __attribute__((aligned(16))) float condin[CPAD];
-    __shared__ __attribute__((aligned(16))) float c1[384];
-    __shared__ __attribute__((aligned(16))) float c2[384];
-    __shared__ __attribute__((aligned(16))) float cond[512];
-    __shared__ __attribute__((aligned(16))) float subin[2 * FG_SUBIN + 8];
-    __shared__ __attribute__((aligned(16))) float skipbuf[FG_SKIP];
-    __shared__ __attribute__((aligned(16))) float hid[3][FG_HOP];
-    __shared__ __attribute__((aligned(16))) float f1[FG_HOP];
-    __shared__ __attribute__((aligned(16))) float part[NT];
-    __shared__ __attribute__((aligned(16))) float part2[NT];
-    __shared__ float prev[FG_PREV];
-    __shared__ float fresh[FG_SUB];
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // FgLds[U]
+    FgLds* L = reinterpret_cast<FgLds*>(lds);
 
     const int tid = threadIdx.x;
     const int g = blockIdx.x % FG_G;          // = XCD under the b % 8 dispatch
@@ -419,105 +487,177 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
     c.epoch = 0;
 
 #pragma unroll 1
-    for (int u = cluster; u < a.B; u += ca.nclusters) {
-        const float* feat = a.features_cl + (size_t)u * T * a.cstride;
-        const float* glob =
-            a.global + (size_t)(a.global_batch == 1 ? 0 : u) * a.G;
-        float* out = a.out + (size_t)u * T * FG_HOP;
-
-        for (int i = tid; i < 3 * FG_HOP; i += NT) (&hid[0][0])[i] = 0.f;
-        for (int i = tid; i < 2 * FG_SUBIN + 8; i += NT) subin[i] = 0.f;
-        for (int i = tid; i < CPAD; i += NT) condin[i] = 0.f;
-        for (int i = tid; i < FG_PREV; i += NT)
-            prev[i] = a.previous
-                ? a.previous[(size_t)(a.previous_batch == 1 ? 0 : u) * FG_PREV + i]
-                : 0.f;
+    for (int u0 = cluster * U; u0 < a.B; u0 += ca.nclusters * U) {
+        // utterances u0 .. u0 + U - 1; slots past the batch replay the last
+        // utterance (same arithmetic, stores masked) so every member of the
+        // cluster runs the same number of exchanges
+        int ut[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            live[u] = u0 + u < a.B;
+            ut[u] = live[u] ? u0 + u : a.B - 1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            for (int i = tid; i < 3 * FG_HOP; i += NT) (&L[u].hid[0][0])[i] = 0.f;
+            for (int i = tid; i < 2 * FG_SUBIN + 8; i += NT) L[u].subin[i] = 0.f;
+            for (int i = tid; i < CPAD; i += NT) L[u].condin[i] = 0.f;
+            for (int i = tid; i < FG_PREV; i += NT)
+                L[u].prev[i] = a.previous
+                    ? a.previous[(size_t)(a.previous_batch == 1 ? 0 : ut[u]) *
+                                     FG_PREV + i]
+                    : 0.f;
+        }
         int base = 0;
         __syncthreads();
 
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
-            const float* row = feat + (size_t)t * a.cstride;
-            if (tid < a.nfeat) condin[tid] = row[tid];
-            else if (tid < nin) condin[tid] = glob[tid - a.nfeat];
-            const int period = (int)rintf(row[a.nfeat]);
+            int period[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float* row =
+                    a.features_cl + ((size_t)ut[u] * T + t) * a.cstride;
+                const float* glob = a.global +
+                    (size_t)(a.global_batch == 1 ? 0 : ut[u]) * a.G;
+                if (tid < a.nfeat) L[u].condin[tid] = row[tid];
+                else if (tid < nin) L[u].condin[tid] = glob[tid - a.nfeat];
+                period[u] = (int)rintf(row[a.nfeat]);
+            }
             __syncthreads();
+            float v[U], m[U];
             // conditioning network: 384 / 384 / 512 rows -> 48 / 48 / 64 each
-            float v = fg_slice<WT, 48, 384>(w.cond[0], condin, condin, CPAD, CPAD, g * 48, part, tid);
-            fg_exchange(c, tanhf(v), g * 48, 48, c1, 384, tid);
-            v = fg_slice<WT, 48, 384>(w.cond[1], c1, c1, CPAD, CPAD, g * 48, part, tid);
-            fg_exchange(c, tanhf(v), g * 48, 48, c2, 384, tid);
-            v = fg_slice<WT, 64, 512>(w.cond[2], c2, c2, CPAD, CPAD, g * 64, part, tid);
-            fg_exchange(c, tanhf(v), g * 64, 64, cond, 512, tid);
+            fg_slice<WT, 48, 384, U>(w.cond[0], lds, FG_OFF(condin), FG_OFF(condin),
+                                     CPAD, CPAD, g * 48, lds, tid, v);
+#pragma unroll
+            for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
+            fg_exchange<U>(c, m, g * 48, 48, lds, FG_OFF(c1), 384, tid);
+            fg_slice<WT, 48, 384, U>(w.cond[1], lds, FG_OFF(c1), FG_OFF(c1), CPAD,
+                                     CPAD, g * 48, lds, tid, v);
+#pragma unroll
+            for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
+            fg_exchange<U>(c, m, g * 48, 48, lds, FG_OFF(c2), 384, tid);
+            fg_slice<WT, 64, 512, U>(w.cond[2], lds, FG_OFF(c2), FG_OFF(c2), CPAD,
+                                     CPAD, g * 64, lds, tid, v);
+#pragma unroll
+            for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
+            fg_exchange<U>(c, m, g * 64, 64, lds, FG_OFF(cond), 512, tid);
 
 #pragma unroll 1
             for (int s = 0; s < 4; ++s) {
-                if (tid < 128) {
-                    subin[tid] = cond[4 * tid + s];
-                } else if (tid < 192) {
-                    const int i = tid - 128;
-                    const float x = prev[(base + FG_PREV - FG_SUB + i) & (FG_PREV - 1)];
-                    subin[128 + i] = x;
-                    skipbuf[1088 + i] = x;
-                } else if (tid < 260) {
-                    const int i = tid - 192;
-                    int idx = FG_PREV - period + i - 2;
-                    if (idx >= FG_PREV) idx -= period;
-                    idx = idx < 0 ? 0 : (idx >= FG_PREV ? FG_PREV - 1 : idx);
-                    const float x = prev[(base + idx) & (FG_PREV - 1)];
-                    subin[192 + i] = x;
-                    if (i >= 2 && i < 66) skipbuf[1024 + i - 2] = x;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    FgLds& S = L[u];
+                    if (tid < 128) {
+                        S.subin[tid] = S.cond[4 * tid + s];
+                    } else if (tid < 192) {
+                        const int i = tid - 128;
+                        const float x =
+                            S.prev[(base + FG_PREV - FG_SUB + i) & (FG_PREV - 1)];
+                        S.subin[128 + i] = x;
+                        S.skipbuf[1088 + i] = x;
+                    } else if (tid < 260) {
+                        const int i = tid - 192;
+                        int idx = FG_PREV - period[u] + i - 2;
+                        if (idx >= FG_PREV) idx -= period[u];
+                        idx = idx < 0 ? 0 : (idx >= FG_PREV ? FG_PREV - 1 : idx);
+                        const float x = S.prev[(base + idx) & (FG_PREV - 1)];
+                        S.subin[192 + i] = x;
+                        if (i >= 2 && i < 66) S.skipbuf[1024 + i - 2] = x;
+                    }
                 }
                 __syncthreads();
 
                 // framewise conv + GLU
-                v = fg_slice<WT, 32, 256>(w.fwconv, subin, subin, 520, 520, g * 32, part, tid);
-                fg_exchange(c, tanhf(v), g * 32, 32, f1, 256, tid);
-                v = fg_slice<WT, 32, 256>(w.fwconv_glu, f1, f1, 256, 256, g * 32, part, tid);
-                fg_exchange(c, tid < 32 ? f1[g * 32 + tid] * fg_sigmoid(v) : 0.f,
-                            g * 32, 32, skipbuf + 768, 256, tid);
+                fg_slice<WT, 32, 256, U>(w.fwconv, lds, FG_OFF(subin), FG_OFF(subin),
+                                         520, 520, g * 32, lds, tid, v);
+#pragma unroll
+                for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
+                fg_exchange<U>(c, m, g * 32, 32, lds, FG_OFF(f1), 256, tid);
+                fg_slice<WT, 32, 256, U>(w.fwconv_glu, lds, FG_OFF(f1), FG_OFF(f1),
+                                         256, 256, g * 32, lds, tid, v);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    m[u] = tid < 32 ? L[u].f1[g * 32 + tid] * fg_sigmoid(v[u]) : 0.f;
+                fg_exchange<U>(c, m, g * 32, 32, lds, FG_OFF(skipbuf) + 768, 256, tid);
 
 #pragma unroll 1
                 for (int n = 0; n < 3; ++n) {
-                    const float* xa = n == 0 ? skipbuf + 768 : skipbuf + (n - 1) * 256;
+                    const int xa = n == 0 ? FG_OFF(skipbuf) + 768
+                                          : FG_OFF(skipbuf) + (n - 1) * 256;
+                    const int hoff = FG_OFF(hid) + n * FG_HOP;
                     // this member's 32 units x 3 gates = packed rows g*96 ..
-                    const float gi = fg_slice<WT, 96, 768>(
-                        w.gru_ih[n], xa, skipbuf + 1024, 256, 384, g * 96, part, tid);
-                    if (tid < 96) part2[tid] = gi;
-                    const float gh = fg_slice<WT, 96, 768>(
-                        w.gru_hh[n], hid[n], hid[n], 256, 256, g * 96, part, tid);
-                    if (tid < 96) part2[96 + tid] = gh;
-                    __syncthreads();
-                    float hnew = 0.f;
-                    if (tid < 32) {
-                        const float r = fg_sigmoid(part2[tid] + part2[96 + tid]);
-                        const float z = fg_sigmoid(part2[32 + tid] + part2[128 + tid]);
-                        const float nn = tanhf(part2[64 + tid] + r * part2[160 + tid]);
-                        hnew = (1.f - z) * nn + z * hid[n][g * 32 + tid];
+                    float gi[U], gh[U];
+                    fg_slice<WT, 96, 768, U>(w.gru_ih[n], lds, xa,
+                                             FG_OFF(skipbuf) + 1024, 256, 384,
+                                             g * 96, lds, tid, gi);
+                    fg_slice<WT, 96, 768, U>(w.gru_hh[n], lds, hoff, hoff, 256, 256,
+                                             g * 96, lds, tid, gh);
+                    if (tid < 96) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            L[u].part2[tid] = gi[u];
+                            L[u].part2[96 + tid] = gh[u];
+                        }
                     }
                     __syncthreads();
-                    fg_exchange(c, hnew, g * 32, 32, hid[n], 256, tid);
-                    v = fg_slice<WT, 32, 256>(w.gru_glu[n], hid[n], hid[n], 256, 256, g * 32, part, tid);
-                    fg_exchange(c, tid < 32 ? hid[n][g * 32 + tid] * fg_sigmoid(v) : 0.f,
-                                g * 32, 32, skipbuf + n * 256, 256, tid);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        float hnew = 0.f;
+                        if (tid < 32) {
+                            const float* p2 = L[u].part2;
+                            const float r = fg_sigmoid(p2[tid] + p2[96 + tid]);
+                            const float z = fg_sigmoid(p2[32 + tid] + p2[128 + tid]);
+                            const float nn = tanhf(p2[64 + tid] + r * p2[160 + tid]);
+                            hnew = (1.f - z) * nn + z * L[u].hid[n][g * 32 + tid];
+                        }
+                        m[u] = hnew;
+                    }
+                    __syncthreads();
+                    fg_exchange<U>(c, m, g * 32, 32, lds, hoff, 256, tid);
+                    fg_slice<WT, 32, 256, U>(w.gru_glu[n], lds, hoff, hoff, 256, 256,
+                                             g * 32, lds, tid, v);
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        m[u] = tid < 32
+                            ? L[u].hid[n][g * 32 + tid] * fg_sigmoid(v[u]) : 0.f;
+                    fg_exchange<U>(c, m, g * 32, 32, lds,
+                                   FG_OFF(skipbuf) + n * 256, 256, tid);
                 }
 
-                v = fg_slice<WT, 32, 256>(w.skip, skipbuf, skipbuf, FG_SKIP, FG_SKIP, g * 32, part, tid);
-                fg_exchange(c, tanhf(v), g * 32, 32, f1, 256, tid);
-                v = fg_slice<WT, 32, 256>(w.skip_glu, f1, f1, 256, 256, g * 32, part, tid);
-                // f1 is both the GLU input and the exchange target: stage
-                // the gated values through part2 first
-                if (tid < 32) part2[tid] = f1[g * 32 + tid] * fg_sigmoid(v);
+                fg_slice<WT, 32, 256, U>(w.skip, lds, FG_OFF(skipbuf), FG_OFF(skipbuf),
+                                         FG_SKIP, FG_SKIP, g * 32, lds, tid, v);
+#pragma unroll
+                for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
+                fg_exchange<U>(c, m, g * 32, 32, lds, FG_OFF(f1), 256, tid);
+                fg_slice<WT, 32, 256, U>(w.skip_glu, lds, FG_OFF(f1), FG_OFF(f1), 256,
+                                         256, g * 32, lds, tid, v);
+                // f1 is both the GLU input and the exchange target: the gated
+                // values are complete (barrier) before anyone overwrites it
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    m[u] = tid < 32 ? L[u].f1[g * 32 + tid] * fg_sigmoid(v[u]) : 0.f;
                 __syncthreads();
-                fg_exchange(c, tid < 32 ? part2[tid] : 0.f, g * 32, 32, f1, 256, tid);
-                v = fg_slice<WT, 8, 64>(w.out, f1, f1, 256, 256, g * 8, part, tid);
-                const float sample = tanhf(v);
-                if (tid < 8) out[(size_t)t * FG_HOP + s * FG_SUB + g * 8 + tid] = sample;
-                fg_exchange(c, sample, g * 8, 8, fresh, FG_SUB, tid);
-                if (tid < FG_SUB) {
-                    prev[(base + tid) & (FG_PREV - 1)] = fresh[tid];
-                } else if (tid >= 256 && tid < 256 + FG_SUBIN) {
-                    subin[FG_SUBIN + tid - 256] = subin[tid - 256];
+                fg_exchange<U>(c, m, g * 32, 32, lds, FG_OFF(f1), 256, tid);
+                fg_slice<WT, 8, 64, U>(w.out, lds, FG_OFF(f1), FG_OFF(f1), 256, 256,
+                                       g * 8, lds, tid, v);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    m[u] = tanhf(v[u]);
+                    if (tid < 8 && live[u])
+                        a.out[((size_t)ut[u] * T + t) * FG_HOP + s * FG_SUB +
+                              g * 8 + tid] = m[u];
+                }
+                fg_exchange<U>(c, m, g * 8, 8, lds, FG_OFF(fresh), FG_SUB, tid);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    FgLds& S = L[u];
+                    if (tid < FG_SUB) {
+                        S.prev[(base + tid) & (FG_PREV - 1)] = S.fresh[tid];
+                    } else if (tid >= 256 && tid < 256 + FG_SUBIN) {
+                        S.subin[FG_SUBIN + tid - 256] = S.subin[tid - 256];
+                    }
                 }
                 base = (base + FG_SUB) & (FG_PREV - 1);
                 __syncthreads();

@@ -1,5 +1,6 @@
-"""FARGAN throughput (config 5): batch x 10 s utterances, one persistent
-workgroup per utterance. Run on the GPU box."""
+"""FARGAN throughput (config 5): batch x 10 s utterances. Run on the GPU box.
+PM_FARGAN=single|cluster forces a kernel, BATCHES=1,32,... picks the sizes."""
+import os
 import json
 import sys
 import time
@@ -20,7 +21,7 @@ for dtype in ('fp32', 'f16'):
     promonet_amd.configure(MODEL='fargan', FARGAN_WEIGHT_DTYPE=dtype)
     torch.manual_seed(0)
     model = promonet_amd.model.Generator().to(device).eval()
-    for batch in (1, 32, 256):
+    for batch in [int(b) for b in os.environ.get('BATCHES', '1,32,256').split(',')]:
         inputs = synthetic_inputs(batch, frames, 1234, device)
         with torch.inference_mode():
             model(*inputs, None)

@@ -64,12 +64,14 @@ def test_matches_reference_golden(
     model.model.kernel_mode = 0
 
 
-def test_cluster_waves_and_determinism(device, fargan_model):
-    """More utterances than clusters (each cluster walks several utterances,
-    its arrival counter keeps counting), repeated runs bit-identical, and the
-    two kernels agree."""
+@pytest.mark.parametrize('batch', [37, 70, 135])
+def test_cluster_waves_and_determinism(device, fargan_model, batch):
+    """More utterances than clusters: 2 (batch 37, one padded slot) or 4
+    (batch 70, two padded slots) utterances advance in lockstep per cluster,
+    and at 135 the 32 clusters walk a second wave with their epochs still
+    counting. Repeated runs bit-identical, and the two kernels agree."""
     model = fargan_model('fp32')
-    inputs = on(device, oracle.synthetic_inputs(37, 6, seed=15))
+    inputs = on(device, oracle.synthetic_inputs(batch, 6, seed=15))
     with torch.inference_mode():
         model.model.kernel_mode = 2
         clustered = model(*inputs, None)
