@@ -1418,10 +1418,17 @@ static int fargan_launch(
         const dim3 grid(ca.nclusters * FG_G), block(FG_THREADS);
         const size_t smem = (size_t)U * sizeof(FgLds);
         auto launch = [&](auto kern) -> hipError_t {
-            hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(kern),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) return e;
+            // (the three U variants share one function type, hence one lambda
+            // instantiation: the flag is per U)
+            static bool attr_done[FG_UMAX + 1] = {};
+            bool& attr_set = attr_done[U];
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(kern),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) return e;
+                attr_set = true;
+            }
             hipLaunchKernelGGL(kern, grid, block, smem, s, ca, w);
             return hipGetLastError();
         };
