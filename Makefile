@@ -1,7 +1,13 @@
 # Build libpromonet_hip.so (gfx950) and nothing else. `make -j4`.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
+# TUNING=1: A/B scaffolding (PM_FUSION / PM_NO_NARROW / PM_FARGAN environment
+# switches, phase-timeline stamps, ablation defines). Never in the shipped .so.
+TUNING ?= 0
 CXXFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-value -fno-honor-nans
+ifeq ($(TUNING),1)
+CXXFLAGS += -DPM_TUNING
+endif
 SRC = promonet_amd/csrc
 OBJ = build/obj
 LIB = promonet_amd/lib/libpromonet_hip.so
@@ -17,6 +23,11 @@ $(OBJ)/%.o: $(SRC)/%.hip $(HDRS)
 $(LIB): $(OBJS)
 	@mkdir -p promonet_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+	@python3 scripts/check_spills.py $(OBJS) || true
+
+# fails when any kernel spills VGPRs or uses scratch memory
+check: $(LIB)
+	python3 scripts/check_spills.py $(OBJS)
 
 clean:
 	rm -rf build $(LIB)

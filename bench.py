@@ -1,23 +1,30 @@
 """Benchmark of the synthesis hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f16|bf16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--model hifigan|fargan] [--dtype f16|bf16|fp32]
+                    [--batch B] [--seconds S]
 
-One "step" = one pass of `Generator.forward` (feature preparation + HiFi-GAN
-vocoder, the scope of the reference's 'generate' timer,
+One "step" = one pass of `Generator.forward` (feature preparation + vocoder,
+the scope of the reference's 'generate' timer,
 promonet/synthesize/core.py:250-281) over one batch of 32 synthetic 10 s
 utterances per GPU (BASELINE.json configs[2]: 861 frames, 220 416 samples
 each), inputs resident in HBM, plus - for N > 1 - the all-gather of the
 generated audio over xGMI (RCCL). Weights are random-init (no checkpoint is
 reachable offline), broadcast from rank 0. Prints ONE JSON line on rank 0.
 
-For N > 1 launch with
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+`--gpus N` with N > 1 and no torchrun environment re-launches this script as
+N ranks (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ...`); under torchrun it uses the environment it is
+given. Other BASELINE.json configs: `--dtype fp32 --batch 8 --seconds 5`
+(config 2), `--model fargan` (config 5).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -33,6 +40,11 @@ from promonet_amd import _lib  # noqa: E402
 
 FLOP_PER_SAMPLE = 2_399_772          # conv + convT MACs x 2
 ELEMENTS_PER_SAMPLE = 5_101.4        # layer-granular activation elements
+FARGAN_FLOP_PER_SAMPLE = 73_843
+# FARGAN weights read per dependent sub-frame step (fargan.py:199-335): framewise
+# conv 256x520 + its GLU 256x256, 3 x (GRU 768x384 + 768x256 + GLU 256x256),
+# skip 256x1152 + GLU, output 64x256; + 1/4 of the per-frame conditioning net
+FARGAN_WEIGHTS = 2_246_656 + (2 * 371 * 371 + 512 * 371) // 4
 PEAK_TFLOPS = {'f16': 2500., 'bf16': 2500., 'fp32': 157.3}   # dense MFMA
 PEAK_HBM_GBS = 8000.
 # sustained register-resident MFMA rate on random operands under the power cap
@@ -46,14 +58,36 @@ def parse_args():
     parser.add_argument('--gpus', type=int, default=1)
     parser.add_argument('--steps', type=int, default=10)
     parser.add_argument('--warmup', type=int, default=3)
+    parser.add_argument('--model', default='hifigan',
+                        choices=['hifigan', 'fargan'])
     parser.add_argument('--dtype', default='f16',
-                        choices=['f16', 'bf16', 'fp32'])
+                        choices=['f16', 'bf16', 'fp32'],
+                        help='MFMA operand type (hifigan) / stored weight '
+                             'type f16|fp32 (fargan; its math is fp32)')
     parser.add_argument('--batch', type=int, default=32,
                         help='utterances per GPU')
     parser.add_argument('--seconds', type=float, default=10.)
+    parser.add_argument('--sustain', type=float, default=5.,
+                        help='seconds of back-to-back steps timed after the '
+                             'K official ones (steady-state clocks); 0 = off')
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--no-gather', action='store_true')
     return parser.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: become the launcher."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    command = [
+        sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+        f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+        '--master-port', str(port), str(Path(__file__).resolve())
+    ] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    raise SystemExit(subprocess.run(command, env=env).returncode)
 
 
 def synthetic_inputs(batch, frames, seed, device):
@@ -72,46 +106,60 @@ def synthetic_inputs(batch, frames, seed, device):
         loudness, pitch, periodicity, ppg, speakers, ones, ones.clone())]
 
 
-def cpu_baseline():
-    """The CPU oracle (a port of the reference's op sequence in PyTorch
-    fp32) timed on this host's cores on a bounded sample of the workload."""
+def cpu_baseline(model_name, budget=60.):
+    """The CPU oracle (a port of the reference's op sequence in PyTorch fp32)
+    timed on this host's cores: BASELINE.json config 2's shape (batch 8 x 5 s;
+    FARGAN: 2 x 1 s), at os.cpu_count() torch threads and at 8, median of up
+    to 3 runs after 1 warm-up, bounded by `budget` seconds of CPU work in all
+    (a reported baseline, not the target)."""
     sys.path.insert(0, str(ROOT / 'oracle'))
     import restatement as oracle
-    batch, frames = 4, 430          # 4 x 5 s of audio per run
-    state = oracle.random_state(seed=0)
+    if model_name == 'fargan':
+        batch, frames = 2, 86
+        state = oracle.random_state_fargan(seed=0)
+        forward = oracle.fargan_generator_forward
+        name = 'fargan_generator_forward'
+    else:
+        batch, frames = 8, 430
+        state = oracle.random_state(seed=0)
+        forward = oracle.generator_forward
+        name = 'generator_forward'
     inputs = oracle.synthetic_inputs(batch, frames, seed=1234)
     samples = batch * frames * promonet_amd.HOPSIZE
     cpus = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    # oneDNN does not scale to every core on this small a problem: time a few
-    # thread counts (bounded: ~10-30 s in total) and report the fastest
-    best = None
-    tried = {}
+    by_threads, runs_by_threads = {}, {}
+    settings = sorted({cpus, min(8, cpus)}, reverse=True)
+    spent = 0.
     with torch.inference_mode():
-        for threads in sorted({min(t, cpus) for t in (16, 32, 64, default_threads)}):
+        for threads in settings:
             torch.set_num_threads(threads)
-            oracle.generator_forward(*inputs, state)           # warm-up
+            allotted = budget / len(settings)
+            start = time.perf_counter()
+            forward(*inputs, state)                         # warm-up
+            used = time.perf_counter() - start
             times = []
-            for _ in range(2):
+            while len(times) < 3 and (not times or used + times[-1] < allotted):
                 start = time.perf_counter()
-                oracle.generator_forward(*inputs, state)
+                forward(*inputs, state)
                 times.append(time.perf_counter() - start)
-            seconds = min(times)
-            tried[threads] = samples / seconds
-            if best is None or seconds < best[1]:
-                best = (threads, seconds)
+                used += times[-1]
+            spent += used
+            by_threads[threads] = samples / statistics.median(times)
+            runs_by_threads[threads] = len(times)
     torch.set_num_threads(default_threads)
-    threads, seconds = best
+    threads = max(by_threads, key=by_threads.get)
     return {
-        'value': samples / seconds, 'unit': 'samples/s', 'cores': threads,
+        'value': by_threads[threads], 'unit': 'samples/s', 'cores': threads,
         'kind': 'port',
-        'rtf': samples / promonet_amd.SAMPLE_RATE / seconds,
-        'samples_per_s_by_threads': tried,
-        'sample': f'oracle/restatement.py generator_forward (PyTorch CPU port '
-                  f'of the reference op sequence), fp32, batch {batch} x '
-                  f'{frames} frames (5 s each), best of 2 after 1 warm-up at '
-                  f'the fastest of {sorted(tried)} torch threads on '
-                  f'{cpus} cpus'}
+        'rtf': by_threads[threads] / promonet_amd.SAMPLE_RATE,
+        'samples_per_s_by_threads': by_threads,
+        'timed_runs_by_threads': runs_by_threads,
+        'sample': f'oracle/restatement.py {name} (PyTorch CPU port of the '
+                  f'reference op sequence), fp32, batch {batch} x {frames} '
+                  f'frames, median of the timed runs after 1 warm-up at '
+                  f'{sorted(by_threads)} torch threads on {cpus} cpus '
+                  f'({spent:.0f} s of CPU work); value = the faster setting'}
 
 
 def parse_profile(text):
@@ -126,20 +174,31 @@ def parse_profile(text):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
     rank, world, device = promonet_amd.distributed.init()
-    assert world == args.gpus, f'WORLD_SIZE {world} != --gpus {args.gpus}'
+    if world != args.gpus:
+        raise SystemExit(
+            f'bench.py: WORLD_SIZE {world} != --gpus {args.gpus}')
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an AMD GPU')
+    fargan = args.model == 'fargan'
 
     frames = promonet_amd.convert.seconds_to_frames(args.seconds)
     samples_per_step = args.batch * frames * promonet_amd.HOPSIZE
 
-    promonet_amd.configure(COMPUTE_DTYPE=args.dtype)
+    if fargan:
+        weight_dtype = 'f16' if args.dtype == 'f16' else 'fp32'
+        promonet_amd.configure(MODEL='fargan', FARGAN_WEIGHT_DTYPE=weight_dtype)
+    else:
+        promonet_amd.configure(COMPUTE_DTYPE=args.dtype)
     torch.manual_seed(0)
     model = promonet_amd.model.Generator().to(device).eval()
     promonet_amd.distributed.broadcast_model(model)     # RCCL broadcast
     inputs = synthetic_inputs(args.batch, frames, 1234 + rank, device)
     gather = world > 1 and not args.no_gather
+    backend = dist.get_backend() if world > 1 else None
+    overlap = gather and backend == 'nccl'
     if gather:
         # The all-gather of step k runs on RCCL's stream while step k + 1
         # computes: two destination buffers, one is reused only after its
@@ -157,16 +216,18 @@ def main():
         if gather:
             slot = counter[0] & 1
             counter[0] += 1
-            if pending[slot] is not None:
+            if pending[slot] is not None and pending[slot][0] is not None:
                 pending[slot][0].wait()
-            pending[slot] = (dist.all_gather_into_tensor(
-                gathered[slot], audio, async_op=True), audio)
+            work, _ = promonet_amd.distributed.all_gather_into(
+                audio, world, out=gathered[slot], async_op=True)
+            pending[slot] = (work, audio)
         return audio
 
     def drain():
         for slot in range(2):
             if pending[slot] is not None:
-                pending[slot][0].wait()
+                if pending[slot][0] is not None:
+                    pending[slot][0].wait()
                 pending[slot] = None
 
     def fence():
@@ -176,74 +237,171 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    library = _lib.lib()
+    engine = None
+    forward_events = []
     with torch.inference_mode():
         for _ in range(args.warmup):
             step()
-        engine = model.model.engine()
-        library = _lib.lib()
-        library.pm_hifigan_profile_reset(engine)
-        library.pm_hifigan_profile_enable(engine, 1)
+        if not fargan:
+            engine = model.model.engine()
+            library.pm_hifigan_profile_reset(engine)
+            library.pm_hifigan_profile_enable(engine, 1)
         fence()
         start = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            if fargan:
+                # HIP events on the launch stream (torch's current stream is
+                # the one the C ABI is handed) around the forward's launches
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                step()
+                e1.record()
+                forward_events.append((e0, e1))
+            else:
+                step()
         fence()
         elapsed = time.perf_counter() - start
-        library.pm_hifigan_profile_enable(engine, 0)
-        library.pm_hifigan_profile_collect(engine)
-    profile = parse_profile(
-        library.pm_hifigan_profile_report(engine).decode())
+        if not fargan:
+            library.pm_hifigan_profile_enable(engine, 0)
+            library.pm_hifigan_profile_collect(engine)
+        # steady state: the official region can be shorter than the DVFS /
+        # power-cap settling time, so also time >= `sustain` seconds of
+        # back-to-back steps (reported beside, never instead of, `value`)
+        sustained = None
+        if args.sustain > 0:
+            per_step = max(elapsed / args.steps, 1e-4)
+            count = max(args.steps, int(math.ceil(args.sustain / per_step)))
+            fence()
+            begin = time.perf_counter()
+            for _ in range(count):
+                step()
+            fence()
+            sustained = (time.perf_counter() - begin, count)
 
     if world > 1:
-        worst = torch.tensor([elapsed], device=device)
+        worst = torch.tensor(
+            [elapsed, sustained[0] if sustained else 0.], device=device)
+        worst = worst.cpu() if backend == 'gloo' else worst
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-        elapsed = worst.item()
+        elapsed = worst[0].item()
+        if sustained:
+            sustained = (worst[1].item(), sustained[1])
 
     if rank == 0:
         total_samples = world * samples_per_step * args.steps
         value = total_samples / elapsed
         per_gpu = value / world
-        # dominant kernel family (HIP events around every launch, on the
-        # launch stream, inside the timed region)
-        label, row = max(profile.items(), key=lambda kv: kv[1]['ms'])
-        avg_ms = row['ms'] / row['launches']
-        flops_per_launch = row['flops'] / row['launches']
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        traffic = None
-        traffic_file = ROOT / 'profiles' / 'traffic.json'
-        if traffic_file.exists() and args.batch == 32 and frames == 861:
-            traffic = json.loads(traffic_file.read_text()).get(
-                f'{label}:{args.dtype}')
-        kernel_ms = sum(r['ms'] for r in profile.values()) / args.steps
+        dtype = ('f32' if fargan else args.dtype)
+        if fargan:
+            workload = (
+                f'Generator.forward (prepare_features + FARGAN, '
+                f'config/fargan.py), batch {args.batch} x {args.seconds:g} s '
+                f'per GPU ({frames} frames = {frames * 4} dependent sub-frame '
+                f'steps), random-init weights stored as '
+                f'{promonet_amd.FARGAN_WEIGHT_DTYPE}, fp32 arithmetic')
+        else:
+            workload = (
+                f'Generator.forward (prepare_features + HiFi-GAN), '
+                f'batch {args.batch} x {args.seconds:g} s per GPU '
+                f'({frames} frames, {frames * 256} samples each), '
+                f'random-init weights, {args.dtype} MFMA operands, '
+                f'fp32 accumulate and activations')
         result = {
             'metric': f'audio samples/sec (22.05 kHz), batch-{args.batch} '
                       f'{args.seconds:g} s utterances',
             'value': value,
             'unit': 'samples/s',
             'n_gpus': world,
+            'world_size': dist.get_world_size() if world > 1 else 1,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': args.dtype,
+            'dtype': dtype,
             'data': 'synthetic',
             'config': {
-                'workload': f'Generator.forward (prepare_features + HiFi-GAN), '
-                            f'batch {args.batch} x {args.seconds:g} s per GPU '
-                            f'({frames} frames, {frames * 256} samples each), '
-                            f'random-init weights, {args.dtype} MFMA operands, '
-                            f'fp32 accumulate and activations',
+                'workload': workload,
+                'model': args.model,
                 'batch_per_gpu': args.batch,
                 'frames': frames,
+                'backend': backend,
+                'devices': torch.cuda.device_count(),
                 'parallelism': f'batch-sharded x{world}' + (
                     ' + RCCL all-gather of audio (overlapped with the next '
-                    'step, drained inside the timed region)' if gather else '')},
+                    'step, drained inside the timed region)' if overlap else
+                    ' + all-gather of audio staged through host memory over '
+                    'gloo (more ranks than GPUs: test-box mode)' if gather
+                    else '')},
             'rtf': value / promonet_amd.SAMPLE_RATE,
             'samples_per_sec_per_gpu': per_gpu,
             'rtf_per_gpu': per_gpu / promonet_amd.SAMPLE_RATE,
-            'roofline': {
+        }
+        if not fargan and args.dtype == 'f16':
+            result['dtype_note'] = (
+                'BASELINE.json configs[2] names bf16; f16 operands run at the '
+                'same MFMA rate and byte width and meet the 1e-4 max-abs gate '
+                '(tests/test_gpu_model.py::test_full_size_*), plain bf16 '
+                'operands do not (DESIGN.md section 3); --dtype bf16 runs them')
+        if sustained:
+            seconds, count = sustained
+            result['sustained_ms_per_step'] = seconds / count * 1e3
+            result['sustained_steps'] = count
+            result['sustained_value'] = \
+                world * samples_per_step * count / seconds
+        if fargan:
+            times = [a.elapsed_time(b) for a, b in forward_events]
+            avg_ms = sum(times) / len(times)
+            steps = frames * 4
+            wbytes = FARGAN_WEIGHTS * (
+                2 if promonet_amd.FARGAN_WEIGHT_DTYPE == 'f16' else 4)
+            # compulsory HBM bytes of one launch: features in, audio out, the
+            # weights once (they stay L2-resident for all 3 444 steps)
+            hbm_bytes = args.batch * frames * (128 * 4 + 256 * 4) + wbytes
+            clusters = min(32, args.batch)
+            result['roofline'] = {
+                'kernel': 'pm_fargan_cluster_kernel',
+                'bound': 'hbm',
+                'achieved': hbm_bytes / (avg_ms * 1e-3) / 1e9,
+                'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': hbm_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                'traffic': None,
+                'avg_launch_ms': avg_ms,
+                'algorithmic_bytes_per_launch': hbm_bytes,
+                'note': 'latency-bound recurrence, neither HBM nor MFMA: '
+                        'see latency_model',
+                'latency_model': {
+                    'dependent_steps': steps,
+                    'us_per_step': avg_ms * 1e3 / steps,
+                    'l2_weight_stream_gbs':
+                        wbytes * steps * clusters / (avg_ms * 1e-3) / 1e9,
+                    'l2_peak_gbs': 34500.,
+                    'tflops': per_gpu * FARGAN_FLOP_PER_SAMPLE / 1e12}}
+        else:
+            profile = parse_profile(
+                library.pm_hifigan_profile_report(engine).decode())
+            # dominant kernel family (HIP events around every launch, on the
+            # launch stream, inside the timed region)
+            label, row = max(profile.items(), key=lambda kv: kv[1]['ms'])
+            avg_ms = row['ms'] / row['launches']
+            flops_per_launch = row['flops'] / row['launches']
+            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            traffic, measured_step_bytes = None, None
+            traffic_file = ROOT / 'profiles' / 'traffic.json'
+            if traffic_file.exists() and args.batch == 32 and frames == 861:
+                table = json.loads(traffic_file.read_text())
+                traffic = table.get(f'{label}:{args.dtype}')
+                per_step = [
+                    table.get(f'{k}:{args.dtype}') for k in profile]
+                if all(v is not None for v in per_step):
+                    measured_step_bytes = sum(
+                        v * profile[k]['launches'] / args.steps
+                        for k, v in zip(profile, per_step))
+            kernel_ms = sum(r['ms'] for r in profile.values()) / args.steps
+            result['roofline'] = {
                 'kernel': label,
                 'bound': 'mfma',
                 'achieved': achieved,
@@ -262,24 +420,34 @@ def main():
                 'algorithmic_gbs': row['bytes'] / row['launches'] /
                                    (avg_ms * 1e-3) / 1e9,
                 'share_of_kernel_time': row['ms'] / sum(
-                    r['ms'] for r in profile.values())},
-            'whole_path': {
+                    r['ms'] for r in profile.values())}
+            result['whole_path'] = {
                 'tflops': per_gpu * FLOP_PER_SAMPLE / 1e12,
                 'frac_of_mfma_peak': per_gpu * FLOP_PER_SAMPLE / 1e12 /
                                      PEAK_TFLOPS[args.dtype],
-                'layer_granular_gbs': per_gpu * ELEMENTS_PER_SAMPLE * 4 / 1e9,
-                'frac_of_hbm_peak': per_gpu * ELEMENTS_PER_SAMPLE * 4 / 1e9 /
-                                    PEAK_HBM_GBS,
-                'kernel_ms_per_step': kernel_ms},
-            'kernels': {
+                # HBM bytes the kernels really moved per step (rocprofv3 PMC,
+                # FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic.json) over
+                # this run's step time: the ACHIEVED HBM rate
+                'measured_hbm_gbs': (
+                    measured_step_bytes / (elapsed / args.steps) / 1e9
+                    if measured_step_bytes else None),
+                'measured_frac_of_hbm_peak': (
+                    measured_step_bytes / (elapsed / args.steps) / 1e9 /
+                    PEAK_HBM_GBS if measured_step_bytes else None),
+                # a MODEL, not a measurement: the bytes an unfused
+                # layer-by-layer implementation would move
+                # at this step time; the fused kernels move far fewer
+                'unfused_layer_model_gbs':
+                    per_gpu * ELEMENTS_PER_SAMPLE * 4 / 1e9,
+                'kernel_ms_per_step': kernel_ms}
+            result['kernels'] = {
                 k: {'ms_per_step': v['ms'] / args.steps,
                     'launches_per_step': v['launches'] // args.steps,
                     'tflops': v['flops'] / max(v['ms'], 1e-9) / 1e9,
                     'gbs': v['bytes'] / max(v['ms'], 1e-9) / 1e6}
-                for k, v in sorted(profile.items())},
-        }
+                for k, v in sorted(profile.items())}
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline()
+            result['cpu_baseline'] = cpu_baseline(args.model)
         print(json.dumps(result))
 
     if world > 1:

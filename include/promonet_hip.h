@@ -131,31 +131,53 @@ int pm_hifigan_profile_reset(pm_hifigan_t h);
 const char* pm_hifigan_profile_report(pm_hifigan_t h);
 
 /* ---- conditioning: replaces Generator.prepare_features ------------------
- * (promonet/model/generator.py:137-197, default config) incl. the
- * third-party ppgs.sparsify('percentile') it calls (:140-147).
+ * (promonet/model/generator.py:137-197) incl. the third-party ppgs.sparsify
+ * it calls (:140-147).
  *   loudness (B, F, T) dB with F == bands or any F >= bands (513)
  *   pitch (B, T) Hz, periodicity (B, T), ppg (B, P, T)
  *   pitch_edges (NB) = Generator.pitch_distribution, pitch_table (NB, E)
  *   out_ref (B, P+E+bands+1, T) and/or out_cl (B, T, C_pad); either may be
  *   NULL. period_rate > 0 appends the channel period_rate / clip(hz), the
- *   pitch period in samples FARGAN reads (generator.py:191-195).          */
+ *   pitch period in samples FARGAN reads (generator.py:191-195).
+ *   sparse_method = promonet.SPARSE_PPG_METHOD: PM_SPARSE_NONE (ppg passed
+ *   through), _PERCENTILE (ppg_threshold = quantile in [0, 1], the default
+ *   0.85), _CONSTANT (ppg_threshold = the cut itself), _TOPK (ppg_threshold
+ *   = k, the number of entries kept per frame).                            */
+#define PM_SPARSE_NONE 0
+#define PM_SPARSE_PERCENTILE 1
+#define PM_SPARSE_CONSTANT 2
+#define PM_SPARSE_TOPK 3
 int pm_prepare_features(const float* loudness, const float* pitch,
                         const float* periodicity, const float* ppg,
                         const float* pitch_edges, const float* pitch_table,
                         float* out_ref, float* out_cl, int batch, int frames,
                         int loudness_rows, int ppg_channels, int pitch_bins,
                         int embedding_size, int bands, int cl_channels,
-                        float ppg_threshold, float fmin, float fmax,
-                        float min_db, float ref_db, float period_rate,
-                        void* stream);
+                        int sparse_method, float ppg_threshold, float fmin,
+                        float fmax, float min_db, float ref_db,
+                        float period_rate, void* stream);
 
 /* BaseGenerator.prepare_global_features (generator.py:49-70): speaker
- * embedding lookup + the two augmentation ratios -> (B, S + 2).           */
+ * embedding lookup + the augmentation ratios -> (B, S + 2). Either ratio
+ * pointer may be NULL (AUGMENT_PITCH / AUGMENT_LOUDNESS off: the row is
+ * narrower). speaker_table is (num_speakers, S); an id outside
+ * [0, num_speakers) reads nothing and produces a NaN row.                 */
 int pm_prepare_global_features(const int64_t* speakers,
                                const float* spectral_balance_ratios,
                                const float* loudness_ratios,
                                const float* speaker_table, float* out,
-                               int batch, int speaker_channels, void* stream);
+                               int batch, int speaker_channels,
+                               int num_speakers, void* stream);
+/* ZERO_SHOT variant (generator.py:35-38, synthesize/core.py:253-254): the
+ * speaker is a (B, E) x-vector, the embedding a Linear(E -> S) with weight
+ * (S, E) and bias (S).                                                     */
+int pm_prepare_global_features_linear(const float* speaker_embeddings,
+                                      const float* weight, const float* bias,
+                                      const float* spectral_balance_ratios,
+                                      const float* loudness_ratios,
+                                      float* out, int batch,
+                                      int embedding_channels,
+                                      int speaker_channels, void* stream);
 
 /* ---- per-kernel entry points (unit parity tests; weights in torch layout,
  * packed into `workspace` on every call) --------------------------------- */

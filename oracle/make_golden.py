@@ -27,6 +27,18 @@ def small_config_file():
     return file
 
 
+def variant_config_file(which):
+    """Non-default conditioning variants reachable from the same forward
+    (generator.py:35-38, 97-104, 140-147) on a tiny vocoder."""
+    file = Path(tempfile.gettempdir()) / f'promonet_{which}_config.py'
+    extra = {'zero_shot': 'ZERO_SHOT = True\n',
+             'sparse_none': 'SPARSE_PPG_METHOD = None\n'}[which]
+    file.write_text(
+        f"MODULE = 'promonet'\nCONFIG = '{which}'\n"
+        "HIFIGAN_UPSAMPLE_INITIAL_SIZE = 32\n" + extra)
+    return file
+
+
 def run(which):
     import torch
     import reference_import
@@ -34,6 +46,8 @@ def run(which):
 
     configs = {
         'small': [small_config_file()],
+        'zero_shot': [variant_config_file('zero_shot')],
+        'sparse_none': [variant_config_file('sparse_none')],
         'fargan': [reference_import.REFERENCE_ROOT / 'config' / 'fargan.py'],
     }.get(which, [])
     promonet = reference_import.load(configs)
@@ -75,6 +89,48 @@ def run(which):
                 'previous': previous, 'audio': audio,
                 'period': features[:, -1].clone()}
         torch.save(golden, GOLDEN / 'generator_fargan.pt')
+        return
+
+    if which in ('zero_shot', 'sparse_none'):
+        assert promonet.HIFIGAN_UPSAMPLE_INITIAL_SIZE == 32
+        model = promonet.model.Generator().eval()
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        inputs = list(oracle.synthetic_inputs(2, 20, seed=23))
+        if which == 'zero_shot':
+            assert promonet.ZERO_SHOT and 'speaker_embedding.bias' in state
+            gen = torch.Generator().manual_seed(29)
+            inputs[4] = torch.randn(
+                2, promonet.WAVLM_EMBEDDING_CHANNELS, generator=gen)
+        else:
+            assert promonet.SPARSE_PPG_METHOD is None
+            assert 'ppg_threshold' not in state
+        with torch.inference_mode():
+            features = model.prepare_features(*inputs[:4])
+            global_features = model.prepare_global_features(*inputs[4:7])
+            audio = model(*inputs, model.default_previous_samples)
+            # the restatement, fed the same conditioning variant
+            mine_features = oracle.prepare_features(
+                *inputs[:4], state['pitch_distribution'],
+                state['pitch_embedding.weight'],
+                state.get('ppg_threshold', 0.),
+                'percentile' if which == 'zero_shot' else None)
+            mine_global = oracle.prepare_global_features(
+                *inputs[4:7], state['speaker_embedding.weight'],
+                state.get('speaker_embedding.bias'))
+            mine = oracle.hifigan_forward(mine_features, mine_global, state)
+        assert (features - mine_features).abs().max() < 1e-6
+        assert (global_features - mine_global).abs().max() < 1e-6
+        error = (audio - mine).abs().max().item()
+        print(f'{which}: restatement vs reference max-abs {error:.3e}')
+        assert error < 1e-6
+        torch.save({
+            'config': {'HIFIGAN_UPSAMPLE_INITIAL_SIZE': 32,
+                       'ZERO_SHOT': which == 'zero_shot',
+                       'SPARSE_PPG_METHOD':
+                           None if which == 'sparse_none' else 'percentile'},
+            'state': state, 'inputs': inputs, 'features': features,
+            'global_features': global_features, 'audio': audio},
+            GOLDEN / f'variant_{which}.pt')
         return
 
     if which == 'small':
@@ -234,7 +290,8 @@ if __name__ == '__main__':
     if len(sys.argv) > 1:
         run(sys.argv[1])
     else:
-        for which in ('small', 'default', 'fargan'):
+        for which in ('small', 'default', 'fargan', 'zero_shot',
+                      'sparse_none'):
             subprocess.run(
                 [sys.executable, __file__, which], check=True)
         for file in sorted(GOLDEN.iterdir()):

@@ -77,6 +77,13 @@ def sparsify(ppg, method='percentile', threshold=SPARSE_PPG_THRESHOLD):
         ppg = torch.where(ppg > q, ppg, torch.zeros_like(ppg))
     elif method == 'constant':
         ppg = torch.where(ppg > threshold, ppg, torch.zeros_like(ppg))
+    elif method == 'topk':
+        # keep the k largest entries per frame (ties: lower channel first,
+        # a stable descending sort), zero the rest
+        order = torch.sort(ppg, dim=-2, descending=True, stable=True).indices
+        keep = torch.zeros_like(ppg, dtype=torch.bool)
+        keep.scatter_(-2, order[..., :int(threshold), :], True)
+        ppg = torch.where(keep, ppg, torch.zeros_like(ppg))
     else:
         raise ValueError(f'Sparsify method {method} is not defined')
     return torch.softmax(torch.log(ppg + 1e-8), -2)
@@ -109,15 +116,17 @@ def pitch_bins(pitch, pitch_distribution):
 
 def prepare_features(
     loudness, pitch, periodicity, ppg, pitch_distribution, pitch_embedding,
-    ppg_threshold=SPARSE_PPG_THRESHOLD
+    ppg_threshold=SPARSE_PPG_THRESHOLD, sparse_method='percentile'
 ):
-    """model/generator.py:137-197 (hifigan branch, default config).
+    """model/generator.py:137-197 (hifigan branch; SPARSE_PPG_METHOD
+    'percentile' is the default configuration, None skips sparsify :140-147).
 
     loudness (B, 8|513, T) dB; pitch (B, T) Hz; periodicity (B, T);
     ppg (B, 40, T). Returns (B, 113, T) =
     [ppg 0:40 | pitch-embedding 40:104 | loudness 104:112 | periodicity 112].
     """
-    features = sparsify(ppg, 'percentile', ppg_threshold)
+    features = ppg if sparse_method is None else sparsify(
+        ppg, sparse_method, ppg_threshold)
     bins = pitch_bins(pitch, pitch_distribution)
     embedded = F.embedding(bins, pitch_embedding).permute(0, 2, 1)
     features = torch.cat((features, embedded), dim=1)
@@ -130,12 +139,20 @@ def prepare_features(
 
 
 def prepare_global_features(
-    speakers, spectral_balance_ratios, loudness_ratios, speaker_embedding
+    speakers, spectral_balance_ratios, loudness_ratios, speaker_embedding,
+    speaker_bias=None, augment_pitch=True, augment_loudness=True
 ):
-    """model/generator.py:49-70 (AUGMENT_PITCH and AUGMENT_LOUDNESS on)."""
-    g = F.embedding(speakers, speaker_embedding).unsqueeze(-1)
-    g = torch.cat((g, spectral_balance_ratios[:, None, None]), dim=1)
-    return torch.cat((g, loudness_ratios[:, None, None]), dim=1)
+    """model/generator.py:49-70. Default: Embedding lookup + both ratios;
+    with `speaker_bias` the ZERO_SHOT Linear over x-vectors (:35-38)."""
+    if speaker_bias is None:
+        g = F.embedding(speakers, speaker_embedding).unsqueeze(-1)
+    else:
+        g = F.linear(speakers, speaker_embedding, speaker_bias).unsqueeze(-1)
+    if augment_pitch:
+        g = torch.cat((g, spectral_balance_ratios[:, None, None]), dim=1)
+    if augment_loudness:
+        g = torch.cat((g, loudness_ratios[:, None, None]), dim=1)
+    return g
 
 
 ###############################################################################

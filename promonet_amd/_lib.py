@@ -15,6 +15,7 @@ PM_F32, PM_F16, PM_BF16 = 0, 1, 2
 DTYPES = {'fp32': PM_F32, 'f32': PM_F32, 'f16': PM_F16, 'fp16': PM_F16,
           'bf16': PM_BF16}
 MAX_STAGES, MAX_RESBLOCKS, MAX_DILATIONS = 8, 4, 4
+SPARSE_METHODS = {None: 0, 'percentile': 1, 'constant': 2, 'topk': 3}
 
 c_float_p = ctypes.c_void_p
 c_int64_p = ctypes.POINTER(ctypes.c_int64)
@@ -55,8 +56,9 @@ SIGNATURES = {
     'pm_hifigan_profile_collect': (_I, [_P]),
     'pm_hifigan_profile_reset': (_I, [_P]),
     'pm_hifigan_profile_report': (ctypes.c_char_p, [_P]),
-    'pm_prepare_features': (_I, [_P] * 8 + [_I] * 8 + [_F] * 6 + [_P]),
-    'pm_prepare_global_features': (_I, [_P] * 5 + [_I, _I, _P]),
+    'pm_prepare_features': (_I, [_P] * 8 + [_I] * 9 + [_F] * 6 + [_P]),
+    'pm_prepare_global_features': (_I, [_P] * 5 + [_I, _I, _I, _P]),
+    'pm_prepare_global_features_linear': (_I, [_P] * 6 + [_I, _I, _I, _P]),
     'pm_op_workspace_bytes': (_S, [_I, _I, _I]),
     'pm_block_iteration_cl': (_I, [_I] + [_P] * 6 + [_I] * 6 + [_F, _P, _S, _P]),
     'pm_block_cl': (_I, [_I, _P, _P] + [_P] * 5 + [_I] * 6 + [_F, _P, _S, _P]),

@@ -48,6 +48,7 @@ HIFIGAN_UPSAMPLE_INITIAL_SIZE = 512
 HIFIGAN_UPSAMPLE_KERNEL_SIZES = [16, 16, 4, 4]
 HIFIGAN_UPSAMPLE_RATES = [8, 8, 2, 2]
 SPEAKER_CHANNELS = 256
+WAVLM_EMBEDDING_CHANNELS = 512
 ZERO_SHOT = False
 STEPS = 800000
 NUM_WORKERS = 10

@@ -42,7 +42,9 @@ static int fail(int code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);          \
     } while (0)
 
+#ifdef PM_TUNING
 static unsigned long long* g_timeline = nullptr;   // pm_debug_timeline
+#endif
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -54,7 +56,9 @@ static inline int esz(int dtype) { return dtype == PM_F32 ? 4 : 2; }
 static hipError_t launch_pair(
     int dtype, int C, int K, const PairArgs& a0, hipStream_t s) {
     PairArgs a = a0;
+#ifdef PM_TUNING
     a.timeline = g_timeline;
+#endif
     switch (dtype) {
         case PM_F32: return pm_launch_pair<ElemF32>(C, K, a, s);
         case PM_F16: return pm_launch_pair<ElemF16>(C, K, a, s);
@@ -66,7 +70,9 @@ static hipError_t launch_pair(
 static hipError_t launch_block3(
     int dtype, int C, int K, const Block3Args& a0, hipStream_t s) {
     Block3Args a = a0;
+#ifdef PM_TUNING
     a.timeline = g_timeline;
+#endif
     switch (dtype) {
         case PM_F32: return pm_launch_block3<ElemF32>(C, K, a, s);
         case PM_F16: return pm_launch_block3<ElemF16>(C, K, a, s);
@@ -85,15 +91,19 @@ static hipError_t launch_mrf(
     return hipErrorInvalidValue;
 }
 
-// PM_FUSION=pair forces one kernel per Block iteration everywhere, =block one
-// kernel per Block (no whole-MRF launch) (A/B runs)
+// Fusion level: 2 = whole-MRF launches where they exist, 1 = one kernel per
+// Block, 0 = one kernel per Block iteration. The shipped library always runs
+// level 2; a -DPM_TUNING build reads PM_FUSION=pair|block for A/B runs.
 static int fusion_level() {
-    static int level = -1;
-    if (level < 0) {
+#ifdef PM_TUNING
+    static const int level = [] {
         const char* e = getenv("PM_FUSION");
-        level = (e && !strcmp(e, "pair")) ? 0 : (e && !strcmp(e, "block")) ? 1 : 2;
-    }
+        return (e && !strcmp(e, "pair")) ? 0 : (e && !strcmp(e, "block")) ? 1 : 2;
+    }();
     return level;
+#else
+    return 2;
+#endif
 }
 static bool block3_enabled() {
     return fusion_level() >= 1;
@@ -849,13 +859,16 @@ extern "C" int pm_prepare_features(
     const float* loudness, const float* pitch, const float* periodicity,
     const float* ppg, const float* pitch_edges, const float* pitch_table,
     float* out_ref, float* out_cl, int B, int T, int F, int P, int NB, int E,
-    int bands, int cl_channels, float ppg_threshold, float fmin, float fmax,
-    float min_db, float ref_db, float period_rate, void* stream) {
+    int bands, int cl_channels, int sparse_method, float ppg_threshold,
+    float fmin, float fmax, float min_db, float ref_db, float period_rate,
+    void* stream) {
     if (!loudness || !pitch || !periodicity || !ppg || !pitch_edges ||
         !pitch_table || (!out_ref && !out_cl))
         return fail(PM_EINVAL, "null argument");
     if (B < 1 || T < 1 || P < 2 || bands < 1 || bands > 16 || F < bands)
         return fail(PM_EINVAL, "bad feature dimensions");
+    if (sparse_method < PM_SPARSE_NONE || sparse_method > PM_SPARSE_TOPK)
+        return fail(PM_EINVAL, "sparse_method %d unknown", sparse_method);
     const int C = P + E + bands + 1 + (period_rate > 0.f ? 1 : 0);
     if (out_cl && cl_channels < C)
         return fail(PM_EINVAL, "cl_channels %d < %d", cl_channels, C);
@@ -867,11 +880,22 @@ extern "C" int pm_prepare_features(
     a.Cpad = cl_channels;
     const double step = (double)F / (double)bands;   // generator.py:174
     for (int b = 0; b <= bands; ++b) a.band_start[b] = (int)(b * step);
-    // torch.quantile(..., interpolation='linear') in the tensor's dtype
-    const float rank = ppg_threshold * (float)(P - 1);
-    a.rank_below = (int)floorf(rank);
-    a.rank_above = (int)ceilf(rank);
-    a.rank_weight = rank - floorf(rank);
+    a.sparse_method = sparse_method;
+    a.rank_below = a.rank_above = 0; a.rank_weight = 0.f;
+    a.threshold = ppg_threshold; a.topk = 0;
+    if (sparse_method == PM_SPARSE_PERCENTILE) {
+        if (!(ppg_threshold >= 0.f && ppg_threshold <= 1.f))
+            return fail(PM_EINVAL, "percentile threshold must be in [0, 1]");
+        // torch.quantile(..., interpolation='linear') in the tensor's dtype
+        const float rank = ppg_threshold * (float)(P - 1);
+        a.rank_below = (int)floorf(rank);
+        a.rank_above = (int)ceilf(rank);
+        a.rank_weight = rank - floorf(rank);
+    } else if (sparse_method == PM_SPARSE_TOPK) {
+        a.topk = (int)ppg_threshold;
+        if (a.topk < 1 || a.topk > P)
+            return fail(PM_EINVAL, "topk must be in [1, %d]", P);
+    }
     a.fmin = fmin; a.fmax = fmax; a.min_db = min_db;
     a.db_range = ref_db - min_db;
     a.period_rate = period_rate;
@@ -888,12 +912,28 @@ extern "C" int pm_prepare_features(
 
 extern "C" int pm_prepare_global_features(
     const int64_t* speakers, const float* sbr, const float* lr,
-    const float* table, float* out, int B, int S, void* stream) {
-    if (!speakers || !sbr || !lr || !table || !out)
-        return fail(PM_EINVAL, "null argument");
+    const float* table, float* out, int B, int S, int num_speakers,
+    void* stream) {
+    if (!speakers || !table || !out) return fail(PM_EINVAL, "null argument");
+    if (B < 1 || S < 1 || num_speakers < 1)
+        return fail(PM_EINVAL, "bad dimensions");
     hipLaunchKernelGGL(pm_global_features_kernel, dim3(B), dim3(256), 0,
                        (hipStream_t)stream, (const long long*)speakers, sbr,
-                       lr, table, out, B, S);
+                       lr, table, out, B, S, num_speakers);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" int pm_prepare_global_features_linear(
+    const float* emb, const float* weight, const float* bias,
+    const float* sbr, const float* lr, float* out, int B, int E, int S,
+    void* stream) {
+    if (!emb || !weight || !bias || !out) return fail(PM_EINVAL, "null argument");
+    if (B < 1 || E < 1 || S < 1) return fail(PM_EINVAL, "bad dimensions");
+    hipLaunchKernelGGL(pm_global_features_linear_kernel,
+                       dim3((S + 3) / 4, B), dim3(256), 0,
+                       (hipStream_t)stream, emb, weight, bias, sbr, lr, out, B,
+                       E, S);
     HIP_TRY(hipGetLastError());
     return PM_OK;
 }
@@ -939,11 +979,19 @@ extern "C" int pm_block_iteration_cl(
     return PM_OK;
 }
 
-// Debug: subsequent pair / whole-Block launches make wave 0 of workgroup i
-// write 8 shader-clock stamps to timeline[8 i ..] (NULL switches it off).
+// Debug (-DPM_TUNING builds): subsequent pair / whole-Block launches make
+// wave 0 of workgroup i write 16 shader-clock stamps to timeline[16 i ..]
+// (NULL switches it off). The shipped library has no such instrumentation
+// and returns PM_ESTATE.
 extern "C" int pm_debug_timeline(void* dev_buffer) {
+#ifdef PM_TUNING
     g_timeline = (unsigned long long*)dev_buffer;
     return PM_OK;
+#else
+    (void)dev_buffer;
+    return fail(PM_ESTATE, "pm_debug_timeline needs a -DPM_TUNING build "
+                           "(make TUNING=1)");
+#endif
 }
 
 extern "C" int pm_block_cl(
@@ -1358,19 +1406,40 @@ extern "C" int pm_fargan_finalize(pm_fargan_t h, void* stream) {
 // 8 workgroups take 112 ms for 32 utterances (one per cluster), 162 ms for 64
 // (two in lockstep per cluster), 242 ms for 128 and 485 ms for 256 (four in
 // lockstep, two waves); one workgroup per utterance takes 721 ms per wave of
-// 256 -> clusters at every batch size. PM_FARGAN=single|cluster overrides, as
-// does pm_fargan_set_mode().
+// 256 -> clusters at every batch size, PROVIDED every workgroup of the grid is
+// resident at once: the members of a cluster wait for each other's granules.
+// The grid is therefore sized from the device: one 768-thread workgroup per CU
+// (its LDS / wave budget admits at least that on any gfx950 partition), i.e.
+// at most multiProcessorCount / 8 clusters; a device with fewer than 8 CUs
+// visible gets the one-workgroup-per-utterance kernel. What the query cannot
+// see (another process sharing the GPU, a CU mask) is caught by the bounded
+// spins: pm_fargan_check reports the timeout and the caller re-runs with
+// pm_fargan_set_mode(h, 1). pm_fargan_set_mode() overrides the choice
+// (a -DPM_TUNING build also reads PM_FARGAN=single|cluster).
+static const int FG_MAX_CLUSTERS = 32;   // 32 x 8 workgroups = one per CU
+
+static int fargan_resident_clusters() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
+                              dev) != hipSuccess)
+        return 0;
+    const int n = cus / FG_G;
+    return n < FG_MAX_CLUSTERS ? n : FG_MAX_CLUSTERS;
+}
+
 static bool fargan_use_cluster(pm_fargan_t h, int B) {
-    static int forced = -1;
-    if (forced < 0) {
+    int mode = h->mode;
+#ifdef PM_TUNING
+    static const int forced = [] {
         const char* e = getenv("PM_FARGAN");
-        forced = !e ? 0 : (!strcmp(e, "single") ? 1 : (!strcmp(e, "cluster") ? 2 : 0));
-    }
-    const int mode = h->mode ? h->mode : forced;
-    if (mode == 1) return false;
-    if (mode == 2) return true;
+        return !e ? 0 : (!strcmp(e, "single") ? 1 : (!strcmp(e, "cluster") ? 2 : 0));
+    }();
+    if (!mode) mode = forced;
+#endif
     (void)B;
-    return true;
+    if (mode == 1) return false;
+    return fargan_resident_clusters() >= 1;
 }
 
 extern "C" int pm_fargan_set_mode(pm_fargan_t h, int mode) {
@@ -1378,8 +1447,6 @@ extern "C" int pm_fargan_set_mode(pm_fargan_t h, int mode) {
     h->mode = mode;
     return PM_OK;
 }
-
-static const int FG_MAX_CLUSTERS = 32;   // 32 x 8 workgroups = one per CU
 
 static size_t fargan_state_bytes() {
     return align256((size_t)FG_MAX_CLUSTERS * FG_CSTATE * 4 + 256);
@@ -1409,26 +1476,21 @@ static int fargan_launch(
         ca.f = a;
         ca.state = (unsigned*)cluster_state;
         ca.error = ca.state + (size_t)FG_MAX_CLUSTERS * FG_CSTATE;
-        // U utterances per cluster in lockstep: 1 up to 32 utterances (one
-        // cluster per utterance fills the 256 CUs), then 2, then 4
-        const int U = a.B <= FG_MAX_CLUSTERS ? 1
-                    : a.B <= 2 * FG_MAX_CLUSTERS ? 2 : FG_UMAX;
+        // U utterances per cluster in lockstep: 1 while one cluster per
+        // utterance fits the resident grid (32 clusters = 256 CUs), then 2,
+        // then 4; beyond that the clusters walk the batch in waves
+        const int resident = fargan_resident_clusters();
+        if (resident < 1)
+            return fail(PM_ESTATE, "FARGAN cluster kernel needs >= %d CUs", FG_G);
+        const int U = a.B <= resident ? 1 : a.B <= 2 * resident ? 2 : FG_UMAX;
         const int groups = (a.B + U - 1) / U;
-        ca.nclusters = groups < FG_MAX_CLUSTERS ? groups : FG_MAX_CLUSTERS;
+        ca.nclusters = groups < resident ? groups : resident;
         const dim3 grid(ca.nclusters * FG_G), block(FG_THREADS);
         const size_t smem = (size_t)U * sizeof(FgLds);
         auto launch = [&](auto kern) -> hipError_t {
-            // (the three U variants share one function type, hence one lambda
-            // instantiation: the flag is per U)
-            static bool attr_done[FG_UMAX + 1] = {};
-            bool& attr_set = attr_done[U];
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(kern),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                if (e != hipSuccess) return e;
-                attr_set = true;
-            }
+            hipError_t e = pm_ensure_dynamic_lds(
+                reinterpret_cast<const void*>(kern), (int)smem);
+            if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, block, smem, s, ca, w);
             return hipGetLastError();
         };

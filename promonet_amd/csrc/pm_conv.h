@@ -122,7 +122,7 @@ __device__ __forceinline__ void mma_taps(
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
-#ifdef PM_ABLATE_A   // timing experiment only: no weight stream
+#if defined(PM_TUNING) && defined(PM_ABLATE_A)   // timing experiment only: no weight stream
                     abuf[cur ^ 1][g][mt] = abuf[cur][g][mt];
 #else
                     abuf[cur ^ 1][g][mt] =
@@ -145,7 +145,7 @@ __device__ __forceinline__ void mma_taps(
                 const int j = (step + 1) / KC, kc = (step + 1) % KC;
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
-#ifdef PM_ABLATE_B   // timing experiment only: no LDS operand stream
+#if defined(PM_TUNING) && defined(PM_ABLATE_B)   // timing experiment only: no LDS operand stream
                     bbuf[cb ^ 1][nt] = bbuf[cb][nt];
 #else
                     bbuf[cb ^ 1][nt] = *reinterpret_cast<const frag_t*>(
@@ -169,14 +169,21 @@ __device__ __forceinline__ void mma_taps(
         for (int mt = 0; mt < MTW; ++mt) first[g][mt] = abuf[LAST ^ 1][g][mt];
 }
 
-// Debug instrumentation (pm_debug_timeline): wave 0 of every workgroup stamps
-// the shader clock at phase boundaries; costs one scalar branch when off.
+// Debug instrumentation, -DPM_TUNING builds only (pm_debug_timeline): wave 0
+// of every workgroup stamps the shader clock at phase boundaries. The shipped
+// library carries none of it.
+#ifdef PM_TUNING
+#define PM_TIMELINE_FIELD unsigned long long* timeline;
 #define PM_STAMP(args, i)                                                    \
     do {                                                                     \
         if ((args).timeline && threadIdx.x == 0)                             \
             (args).timeline[(size_t)blockIdx.x * 16 + (i)] =                  \
                 __builtin_amdgcn_s_memtime();                                \
     } while (0)
+#else
+#define PM_TIMELINE_FIELD
+#define PM_STAMP(args, i) ((void)0)
+#endif
 
 // The conv bias rides in the accumulator: the first MFMA of a tile takes the
 // bias vector as its C operand (no zero fill, no add in the epilogue). In the
@@ -226,7 +233,7 @@ struct PairArgs {
     int ntiles;          // tiles per utterance
     const int* lengths;  // (B) valid frames per utterance or null (ragged batch)
     int len_scale;       // samples of this tensor per frame
-    unsigned long long* timeline;   // debug: 16 s_memtime stamps per block
+    PM_TIMELINE_FIELD    // debug stamps (tuning builds)
 };
 
 template <int C, int K, int WN, int NTW>
@@ -646,7 +653,7 @@ struct Block3Args {
     int ntiles, halo, TL;
     const int* lengths;  // (B) valid frames per utterance or null
     int len_scale;
-    unsigned long long* timeline;   // debug: 16 s_memtime stamps per block
+    PM_TIMELINE_FIELD    // debug stamps (tuning builds)
 };
 
 template <class ET, int C, int K, int WM, int WN, int NTW>

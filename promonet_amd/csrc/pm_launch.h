@@ -2,7 +2,43 @@
 // layer shape. Explicitly instantiated once per operand type in
 // pm_conv_{f16,bf16,f32}.hip so the three compile in parallel.
 #pragma once
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "pm_conv.h"
+
+// Opt a kernel into `bytes` of dynamic LDS (> 48 KB needs the attribute).
+// The grant is a property of (kernel, DEVICE): cached per pair, so one process
+// driving several GPUs sets it on each, and guarded so that concurrent
+// launches from several host threads / streams are safe.
+inline hipError_t pm_ensure_dynamic_lds(const void* kern, int bytes) {
+    static std::mutex guard;
+    static std::map<std::pair<const void*, int>, int> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(guard);
+    int& have = granted[std::make_pair(kern, dev)];
+    if (bytes > have) {
+        e = hipFuncSetAttribute(
+            kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        have = bytes;
+    }
+    return hipSuccess;
+}
+
+// Latency (narrow-tile) variants can be switched off for A/B runs in a
+// -DPM_TUNING build only; the shipped library reads no environment.
+inline bool pm_narrow_allowed() {
+#ifdef PM_TUNING
+    static const bool allowed = !getenv("PM_NO_NARROW");
+    return allowed;
+#else
+    return true;
+#endif
+}
 
 template <class ET> hipError_t pm_launch_pair(
     int C, int K, const PairArgs& args, hipStream_t stream);
@@ -80,14 +116,9 @@ static hipError_t launch_pair_cfg(const PairArgs& a0, hipStream_t stream) {
     auto kern = conv_pair_kernel<ET, C, K, WM, WN, NTW, CH, ALIAS>;
     const int smem =
         pair_smem_bytes<ET, C, K, WM, WN, NTW, CH, ALIAS>(a.dilation);
-    static int max_set = 0;
-    if (smem > max_set) {
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(kern),
-            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        max_set = smem;
-    }
+    hipError_t e = pm_ensure_dynamic_lds(
+        reinterpret_cast<const void*>(kern), smem);
+    if (e != hipSuccess) return e;
     const int grid = a.ntiles * a.B;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem,
                        stream, a);
@@ -100,7 +131,7 @@ static hipError_t launch_pair_ck(const PairArgs& a, hipStream_t stream) {
     typedef PairCfgNarrow<ET, C> N;
     if constexpr ((int)N::NTW != (int)W::NTW || (int)N::WN != (int)W::WN) {
         constexpr int TL = W::WN * W::NTW * 32 - (K - 1);
-        static const bool allowed = !getenv("PM_NO_NARROW");
+        const bool allowed = pm_narrow_allowed();
         if (allowed && (long long)((a.L + TL - 1) / TL) * a.B < PM_NARROW_BELOW)
             return launch_pair_cfg<ET, C, K, N>(a, stream);
     }
@@ -200,14 +231,9 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
     a.ntiles = (a.L + a.TL - 1) / a.TL;
     auto kern = conv_block3_kernel<ET, C, K, WM, WN, NTW>;
     constexpr int smem = block3_smem_bytes<ET, C, K, WM, WN, NTW>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(kern),
-            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = pm_ensure_dynamic_lds(
+        reinterpret_cast<const void*>(kern), smem);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.ntiles * a.B), dim3(WM * WN * 64), smem,
                        stream, a);
     return hipGetLastError();
@@ -223,7 +249,7 @@ static hipError_t launch_block3_ck(const Block3Args& a, hipStream_t stream) {
         for (int i = 0; i < a.niter; ++i) halo += (a.dil[i] + 1) * ((K - 1) / 2);
         const int TL = W::WN * W::NTW * 32 - 2 * halo;
         const int TLn = N::WN * N::NTW * 32 - 2 * halo;
-        static const bool allowed = !getenv("PM_NO_NARROW");
+        const bool allowed = pm_narrow_allowed();
         if (allowed && TL > 0 && TLn >= 32 &&
             (long long)((a.L + TL - 1) / TL) * a.B < PM_NARROW_BELOW)
             return launch_block3_cfg<ET, C, K, N>(a, stream);
@@ -265,18 +291,15 @@ static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stre
     for (int j = 0; j < 3; ++j) {
         m.k[j].halo = halo; m.k[j].TL = TL;
         m.k[j].ntiles = (m.k[j].L + TL - 1) / TL;
+#ifdef PM_TUNING
         m.k[j].timeline = nullptr;
+#endif
     }
     auto kern = conv_mrf_kernel<ET, C, WM, WN, NTW, C == 32>;
     constexpr int smem = block3_smem_bytes<ET, C, 11, WM, WN, NTW>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(kern),
-            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = pm_ensure_dynamic_lds(
+        reinterpret_cast<const void*>(kern), smem);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(m.k[0].ntiles * m.k[0].B),
                        dim3(WM * WN * 64), smem, stream, m);
     return hipGetLastError();
@@ -292,7 +315,7 @@ static hipError_t launch_mrf_c(const Block3Args (&blocks)[3], hipStream_t stream
         for (int i = 0; i < blocks[2].niter; ++i) halo += (blocks[2].dil[i] + 1) * 5;
         const int TL = W::WN * W::NTW * 32 - 2 * halo;
         const int TLn = N::WN * N::NTW * 32 - 2 * halo;
-        static const bool allowed = !getenv("PM_NO_NARROW");
+        const bool allowed = pm_narrow_allowed();
         if (allowed && TL > 0 && TLn >= 32 &&
             (long long)((blocks[0].L + TL - 1) / TL) * blocks[0].B < PM_NARROW_BELOW)
             return launch_mrf_cfg<ET, C, N>(blocks, stream);
@@ -361,13 +384,10 @@ static hipError_t launch_single_cfg(const SingleArgs& a0, hipStream_t stream) {
     a.nmblocks = a.M / MB;
     auto kern = conv_single_kernel<ET, KT, KSPAN, CH, WM, WN, MTW, NTW, EPI>;
     constexpr int smem = 2 * (N1 + KSPAN - 1) * (CH * ET::ESZ + 16);
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(kern),
-            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (smem > 48 * 1024) {
+        hipError_t e = pm_ensure_dynamic_lds(
+            reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int grid = a.ntiles * a.nmblocks * a.B;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, stream, a);

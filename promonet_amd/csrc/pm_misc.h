@@ -125,8 +125,11 @@ struct FeatureArgs {
     float* out_ref;            // (B, P + E + bands + 1, T) or null
     int B, T, F, P, NB, E, bands, Cpad;
     int band_start[17];        // int(b * F / bands), b = 0..bands
-    int rank_below, rank_above;  // torch.quantile(linear) gather indices
-    float rank_weight;
+    int sparse_method;         // PM_SPARSE_* (generator.py:140-147)
+    int rank_below, rank_above;  // percentile: torch.quantile(linear) gather
+    float rank_weight;           //   indices and lerp weight
+    float threshold;           // constant: the threshold itself
+    int topk;                  // topk: entries kept per frame
     float fmin, fmax, min_db, db_range;
     float period_rate;         // > 0: append SAMPLE_RATE / hz (FARGAN)
 };
@@ -182,41 +185,67 @@ __global__ __launch_bounds__(256) void pm_prepare_features_kernel(
     }
     __syncthreads();
 
-    // --- ppgs.sparsify(ppg, 'percentile', 0.85)  (generator.py:140-147) ---
-    for (int i = tid; i < P * FRAMES; i += NT) {
-        const int c = i / FRAMES, f = i % FRAMES;
-        const float vi = col[i];
-        int rank = 0;
-        for (int j = 0; j < P; ++j) {
-            const float vj = col[j * FRAMES + f];
-            rank += (vj < vi) || (vj == vi && j < c);
+    // --- ppgs.sparsify(ppg, method, threshold)  (generator.py:140-147) ---
+    // percentile (default): q = per-frame quantile, keep v > q
+    // constant:             keep v > threshold
+    // topk:                 keep the k largest (ties: lower channel first)
+    // then softmax(log(p + 1e-8)) over channels; method None passes ppg on
+    const int method = a.sparse_method;
+    if (method == 1 || method == 3) {
+        for (int i = tid; i < P * FRAMES; i += NT) {
+            const int c = i / FRAMES, f = i % FRAMES;
+            const float vi = col[i];
+            int rank = 0;
+            for (int j = 0; j < P; ++j) {
+                const float vj = col[j * FRAMES + f];
+                rank += (vj < vi) || (vj == vi && j < c);
+            }
+            if (method == 1) {
+                if (rank == a.rank_below) quant[f] = vi;
+                if (rank == a.rank_above) quant[FRAMES + f] = vi;
+            } else {
+                // descending order with index tie-break = ascending rank
+                // counted with the opposite tie-break; keep the top k
+                int above = 0;
+                for (int j = 0; j < P; ++j) {
+                    const float vj = col[j * FRAMES + f];
+                    above += (vj > vi) || (vj == vi && j < c);
+                }
+                row[f * RS + c] = above < a.topk ? vi : 0.f;
+            }
         }
-        if (rank == a.rank_below) quant[f] = vi;
-        if (rank == a.rank_above) quant[FRAMES + f] = vi;
+        __syncthreads();
     }
-    __syncthreads();
     if (tid < FRAMES) {
         const int f = tid;
-        const float below = quant[f], above = quant[FRAMES + f];
-        // torch lerp (weight < 0.5 branch is the one 0.85 * 39 takes)
-        const float wq = a.rank_weight;
-        const float q = wq < 0.5f ? below + wq * (above - below)
-                                  : above - (above - below) * (1.f - wq);
-        float mx = -INFINITY;
-        for (int c = 0; c < P; ++c) {
-            float v = col[c * FRAMES + f];
-            v = v > q ? v : 0.f;
-            v = logf(v + 1e-8f);
-            col[c * FRAMES + f] = v;
-            mx = fmaxf(mx, v);
+        if (method != 0) {
+            float q = a.threshold;
+            if (method == 1) {
+                const float below = quant[f], above = quant[FRAMES + f];
+                // torch lerp (weight < 0.5 branch is the one 0.85 * 39 takes)
+                const float wq = a.rank_weight;
+                q = wq < 0.5f ? below + wq * (above - below)
+                              : above - (above - below) * (1.f - wq);
+            }
+            float mx = -INFINITY;
+            for (int c = 0; c < P; ++c) {
+                float v = col[c * FRAMES + f];
+                if (method == 3) v = row[f * RS + c];
+                else v = v > q ? v : 0.f;
+                v = logf(v + 1e-8f);
+                col[c * FRAMES + f] = v;
+                mx = fmaxf(mx, v);
+            }
+            float sum = 0.f;
+            for (int c = 0; c < P; ++c) {
+                const float ev = expf(col[c * FRAMES + f] - mx);
+                col[c * FRAMES + f] = ev;
+                sum += ev;
+            }
+            stat[f] = sum;
+        } else {
+            stat[f] = 1.f;
         }
-        float sum = 0.f;
-        for (int c = 0; c < P; ++c) {
-            const float ev = expf(col[c * FRAMES + f] - mx);
-            col[c * FRAMES + f] = ev;
-            sum += ev;
-        }
-        stat[f] = sum;
         // periodicity (:187-188), FARGAN pitch period (:191-195)
         row[f * RS + Cb - 1] =
             f < nf ? a.periodicity[(size_t)b * T + t0 + f] : 0.f;
@@ -225,7 +254,7 @@ __global__ __launch_bounds__(256) void pm_prepare_features_kernel(
     __syncthreads();
     for (int i = tid; i < P * FRAMES; i += NT) {
         const int c = i / FRAMES, f = i % FRAMES;
-        row[f * RS + c] = col[i] / stat[f];
+        row[f * RS + c] = method != 0 ? col[i] / stat[f] : col[i];
     }
     // pitch embedding gather (:160-164)
     for (int i = tid; i < a.E * FRAMES; i += NT) {
@@ -264,17 +293,52 @@ __global__ __launch_bounds__(256) void pm_prepare_features_kernel(
 // ---------------------------------------------------------------------------
 // prepare_global_features (generator.py:49-70): embedding row + two ratios
 // ---------------------------------------------------------------------------
+// sbr / lr may be null (AUGMENT_PITCH / AUGMENT_LOUDNESS off): the row is
+// then S (+1) wide. A speaker id outside [0, num_speakers) reads nothing and
+// yields a NaN row (the reference's Embedding raises; NaN audio is the
+// device-side equivalent - the Python layer validates host-side ids first).
 __global__ void pm_global_features_kernel(
     const long long* __restrict__ speakers, const float* __restrict__ sbr,
     const float* __restrict__ lr, const float* __restrict__ table,
-    float* __restrict__ out, int B, int S) {
+    float* __restrict__ out, int B, int S, int num_speakers) {
     const int b = blockIdx.x;
     const long long spk = speakers[b];
+    const bool valid = spk >= 0 && spk < num_speakers;
+    const int W = S + (sbr ? 1 : 0) + (lr ? 1 : 0);
     for (int i = threadIdx.x; i < S; i += blockDim.x)
-        out[(size_t)b * (S + 2) + i] = table[(size_t)spk * S + i];
+        out[(size_t)b * W + i] =
+            valid ? table[(size_t)spk * S + i] : __builtin_nanf("");
     if (threadIdx.x == 0) {
-        out[(size_t)b * (S + 2) + S] = sbr[b];
-        out[(size_t)b * (S + 2) + S + 1] = lr[b];
+        int c = S;
+        if (sbr) out[(size_t)b * W + c++] = sbr[b];
+        if (lr) out[(size_t)b * W + c] = lr[b];
+    }
+}
+
+// ZERO_SHOT speaker conditioning (generator.py:35-38): the speaker "id" is a
+// WavLM x-vector (B, E) and the embedding a Linear(E -> S). One wave per
+// (utterance, output channel), fp32, sequential-in-lane + shuffle reduction.
+__global__ __launch_bounds__(256) void pm_global_features_linear_kernel(
+    const float* __restrict__ emb, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ sbr,
+    const float* __restrict__ lr, float* __restrict__ out, int B, int E,
+    int S) {
+    const int b = blockIdx.y;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int W = S + (sbr ? 1 : 0) + (lr ? 1 : 0);
+    if (m < S) {
+        float s = 0.f;
+        for (int c = lane; c < E; c += 64)
+            s += w[(size_t)m * E + c] * emb[(size_t)b * E + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) out[(size_t)b * W + m] = s + bias[m];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int c = S;
+        if (sbr) out[(size_t)b * W + c++] = sbr[b];
+        if (lr) out[(size_t)b * W + c] = lr[b];
     }
 }
 

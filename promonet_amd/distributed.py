@@ -17,24 +17,37 @@ import torch.distributed as dist
 
 def init(backend=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE /
-    LOCAL_RANK / MASTER_ADDR / MASTER_PORT). Returns (rank, world, device)."""
+    LOCAL_RANK / MASTER_ADDR / MASTER_PORT). Returns (rank, world, device).
+
+    One rank per GPU over RCCL ("nccl"). When there are more local ranks than
+    GPUs (a 1-GPU test box running the 2-rank path) the ranks fold onto the
+    devices round-robin and the backend falls back to gloo - RCCL refuses two
+    ranks on one device - with the collectives staged through host memory."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
     use_gpu = torch.cuda.is_available()
-    # one rank per GPU; the modulo only matters for smoke tests that put
-    # several ranks on a single-GPU box (PROMONET_DIST_BACKEND=gloo)
-    index = local % torch.cuda.device_count() if use_gpu else 0
+    devices = torch.cuda.device_count() if use_gpu else 0
+    index = local % devices if use_gpu else 0
     device = torch.device(f'cuda:{index}' if use_gpu else 'cpu')
     if use_gpu:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        folded = use_gpu and local_world > devices
         backend = backend or os.environ.get('PROMONET_DIST_BACKEND') or (
-            'nccl' if use_gpu else 'gloo')
+            'nccl' if use_gpu and not folded else 'gloo')
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
+
+
+def _host_staged(tensor):
+    """gloo moves host memory: device tensors go through a host copy."""
+    return (
+        dist.is_initialized() and dist.get_backend() == 'gloo' and
+        tensor.is_cuda)
 
 
 def shard_bounds(total, rank, world):
@@ -48,7 +61,8 @@ def shard_bounds(total, rank, world):
 def broadcast_model(model, src=0):
     """Replicate rank `src`'s parameters and buffers on every rank with one
     flat broadcast per dtype (few, large collectives: xGMI links are
-    point-to-point, a ring broadcast is per-link bound)."""
+    point-to-point, a ring broadcast is per-link bound). Every HIP engine
+    packed from the old tensors is dropped, so the next forward repacks."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return model
     tensors = [t for t in list(model.parameters()) + list(model.buffers())]
@@ -57,16 +71,33 @@ def broadcast_model(model, src=0):
         by_dtype.setdefault(tensor.dtype, []).append(tensor)
     for dtype, group in by_dtype.items():
         flat = torch.cat([t.detach().reshape(-1) for t in group])
-        dist.broadcast(flat, src=src)
+        if _host_staged(flat):
+            host = flat.cpu()
+            dist.broadcast(host, src=src)
+            flat = host.to(flat.device)
+        else:
+            dist.broadcast(flat, src=src)
         offset = 0
         with torch.no_grad():
             for tensor in group:
                 count = tensor.numel()
                 tensor.copy_(flat[offset:offset + count].view_as(tensor))
                 offset += count
-    if hasattr(model, 'model') and hasattr(model.model, '_invalidate'):
-        model.model._invalidate()   # repack the HIP engine from new weights
+    invalidate_engines(model)
     return model
+
+
+def invalidate_engines(model):
+    """In-place parameter updates bypass `_apply` and the load_state_dict
+    hooks: drop every packed engine (HiFiGAN / FARGAN, bare or inside a
+    Generator) and every host-side copy of a buffer."""
+    for module in model.modules():
+        if hasattr(module, '_invalidate'):
+            module._invalidate()
+        elif hasattr(module, '_destroy'):
+            module._destroy()
+        if hasattr(module, '_threshold'):
+            module._threshold = None
 
 
 def all_gather_audio(local, total, world=None):
@@ -85,10 +116,7 @@ def all_gather_audio(local, total, world=None):
             (largest - local.shape[0],) + tuple(local.shape[1:]),
             dtype=local.dtype, device=local.device)
         padded = torch.cat((local, pad))
-    gathered = torch.empty(
-        (world * largest,) + tuple(local.shape[1:]), dtype=local.dtype,
-        device=local.device)
-    dist.all_gather_into_tensor(gathered, padded.contiguous())
+    gathered = all_gather_into(padded.contiguous(), world)
     pieces = []
     for rank in range(world):
         start, end = shard_bounds(total, rank, world)
@@ -97,22 +125,47 @@ def all_gather_audio(local, total, world=None):
     return torch.cat(pieces)
 
 
+def all_gather_into(local, world=None, out=None, async_op=False):
+    """Fixed-size all-gather of `local` (n, ...) into (world * n, ...).
+    Returns the gathered tensor, or (work, tensor) when async_op (RCCL only:
+    the collective then runs on RCCL's stream beside the caller's kernels)."""
+    world = world or dist.get_world_size()
+    if out is None:
+        out = torch.empty(
+            (world * local.shape[0],) + tuple(local.shape[1:]),
+            dtype=local.dtype, device=local.device)
+    if _host_staged(local):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu())
+        out.copy_(host)
+        return (None, out) if async_op else out
+    work = dist.all_gather_into_tensor(out, local, async_op=async_op)
+    return (work, out) if async_op else out
+
+
 def synthesize_sharded(
     synthesize, loudness, pitch, periodicity, ppg, speakers,
-    spectral_balance_ratios, loudness_ratios, gather=True
+    spectral_balance_ratios, loudness_ratios, gather=True, hopsize=256
 ):
     """Run `synthesize` on this rank's shard of a (replicated) global batch.
 
     `synthesize(loudness, pitch, periodicity, ppg, speakers, sbr, lr)` ->
     (B_r, 1, S), e.g. `promonet_amd.model.Generator.forward`. Returns the
-    gathered (B, 1, S) audio on every rank (or the local shard).
+    gathered (B, 1, S) audio on every rank (or the local shard). With fewer
+    utterances than ranks the surplus ranks synthesise nothing (the engine
+    rejects empty batches) and contribute an empty shard to the collective.
     """
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     total = pitch.shape[0]
     start, end = shard_bounds(total, rank, world)
-    local = synthesize(
-        loudness[start:end], pitch[start:end], periodicity[start:end],
-        ppg[start:end], speakers[start:end],
-        spectral_balance_ratios[start:end], loudness_ratios[start:end])
+    if end > start:
+        local = synthesize(
+            loudness[start:end], pitch[start:end], periodicity[start:end],
+            ppg[start:end], speakers[start:end],
+            spectral_balance_ratios[start:end], loudness_ratios[start:end])
+    else:
+        local = torch.zeros(
+            0, 1, pitch.shape[-1] * hopsize, dtype=torch.float32,
+            device=pitch.device)
     return all_gather_audio(local, total, world) if gather else local

@@ -35,23 +35,56 @@ def pitch_distribution(dataset=None, partition='train'):
 
 def audio(file):
     """Load mono audio at SAMPLE_RATE as (1, samples) float32
-    (promonet/load.py:16-28 uses torchaudio; wav via scipy here)."""
+    (promonet/load.py:16-28: torchaudio.load + torchaudio.functional.resample
+    + channel mean). torchaudio is not a dependency here: wav files are read
+    with scipy, integer PCM is scaled by 2^(bits - 1) as torchaudio.load
+    (normalize=True) does, and `resample` below restates torchaudio's
+    windowed-sinc resampler (parity unpinned: restated from its published
+    algorithm)."""
     import scipy.io.wavfile
-    import scipy.signal
     rate, data = scipy.io.wavfile.read(file)
     if data.dtype.kind == 'i':
-        data = data.astype(np.float32) / np.iinfo(data.dtype).max
+        data = data.astype(np.float32) / float(
+            2 ** (8 * data.dtype.itemsize - 1))
     elif data.dtype.kind == 'u':
         data = (data.astype(np.float32) - 128.) / 128.
-    data = data.astype(np.float32)
-    if data.ndim == 2:
-        data = data.mean(axis=1)
-    if rate != promonet_amd.SAMPLE_RATE:
-        gcd = np.gcd(rate, promonet_amd.SAMPLE_RATE)
-        data = scipy.signal.resample_poly(
-            data, promonet_amd.SAMPLE_RATE // gcd, rate // gcd
-        ).astype(np.float32)
-    return torch.from_numpy(data)[None]
+    data = torch.from_numpy(np.ascontiguousarray(data.astype(np.float32)))
+    data = data[None] if data.ndim == 1 else data.T      # (channels, samples)
+    data = resample(data, rate, promonet_amd.SAMPLE_RATE)
+    return data.mean(dim=0, keepdim=True)
+
+
+def resample(waveform, orig_freq, new_freq, lowpass_filter_width=6,
+             rolloff=.99):
+    """torchaudio.functional.resample(waveform, orig_freq, new_freq) with its
+    defaults ('sinc_interp_hann', lowpass_filter_width 6, rolloff 0.99):
+    a polyphase bank of Hann-windowed sinc filters applied as one strided
+    conv1d. Host-side file loading only (CPU torch), not on the device path."""
+    import math
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq == new_freq:
+        return waveform
+    gcd = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // gcd, new_freq // gcd
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    index = torch.arange(
+        -width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(
+        0, -new, -1, dtype=torch.float64)[:, None, None] / new + index
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t)
+    kernels = (kernels * window * (base / orig)).to(torch.float32)
+    shape = waveform.shape
+    flat = waveform.reshape(-1, shape[-1]).to(torch.float32)
+    length = flat.shape[-1]
+    padded = torch.nn.functional.pad(flat, (width, width + orig))
+    out = torch.nn.functional.conv1d(padded[:, None], kernels, stride=orig)
+    out = out.transpose(1, 2).reshape(flat.shape[0], -1)
+    target = int(math.ceil(new * length / orig))
+    return out[..., :target].reshape(shape[:-1] + (target,))
 
 
 def ppg(file, resample_length=None):

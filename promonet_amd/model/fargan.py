@@ -167,24 +167,42 @@ class FARGAN(torch.nn.Module):
         out = torch.empty(
             batch, 1, frames * self.hopsize, dtype=torch.float32,
             device=x.device)
-        _lib.check(lib.pm_fargan_set_mode(engine, self.kernel_mode))
         with torch.cuda.device(x.device):
             size = lib.pm_fargan_workspace_bytes(engine, batch, frames)
             if self._workspace is None or self._workspace.numel() < size or \
                     self._workspace.device != x.device:
                 self._workspace = torch.empty(
                     size, dtype=torch.uint8, device=x.device)
-            _lib.check(lib.pm_fargan_forward(
-                engine, _lib.ptr(x), int(channels_last), _lib.ptr(g),
-                g.shape[0], pointer, pbatch, _lib.ptr(out), batch, frames,
-                self._workspace.data_ptr(), self._workspace.numel(),
-                _lib.stream()))
-            if self.check_exchange:
-                # the cluster kernel's inter-workgroup waits are bounded; a
-                # tripped bound must not pass as audio (costs one stream sync)
-                _lib.check(lib.pm_fargan_check(
-                    engine, batch, frames, self._workspace.data_ptr(),
+
+            def launch():
+                _lib.check(lib.pm_fargan_set_mode(engine, self.kernel_mode))
+                _lib.check(lib.pm_fargan_forward(
+                    engine, _lib.ptr(x), int(channels_last), _lib.ptr(g),
+                    g.shape[0], pointer, pbatch, _lib.ptr(out), batch, frames,
+                    self._workspace.data_ptr(), self._workspace.numel(),
                     _lib.stream()))
+                if self.check_exchange:
+                    # the cluster kernel's inter-workgroup waits are bounded;
+                    # a tripped bound must not pass as audio (one stream sync)
+                    _lib.check(lib.pm_fargan_check(
+                        engine, batch, frames, self._workspace.data_ptr(),
+                        _lib.stream()))
+            try:
+                launch()
+            except RuntimeError as error:
+                # The cluster kernel needs all its workgroups resident at
+                # once; a GPU shared with another process (or CU-masked) can
+                # break that and the bounded exchange gives up. Auto mode
+                # then falls back, for good, to one workgroup per utterance.
+                if self.kernel_mode != 0 or 'timed out' not in str(error):
+                    raise
+                import warnings
+                warnings.warn(
+                    'FARGAN cluster exchange timed out (GPU shared or '
+                    'partially masked?); using the one-workgroup-per-'
+                    'utterance kernel from now on')
+                self.kernel_mode = 1
+                launch()
         return out
 
     def remove_weight_norm(self):

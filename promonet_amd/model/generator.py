@@ -29,16 +29,22 @@ class Generator(torch.nn.Module):
         else:
             raise ValueError(
                 f'Generator model {promonet_amd.MODEL} is not defined')
-        if promonet_amd.ZERO_SHOT:
-            raise ValueError('ZERO_SHOT speaker embeddings are not supported')
-        if not (promonet_amd.AUGMENT_PITCH and promonet_amd.AUGMENT_LOUDNESS):
+        # generator.py:35-42: ZERO_SHOT swaps the speaker table for a Linear
+        # over WavLM x-vectors; torch default inits (Embedding N(0, 1))
+        self.zero_shot = bool(promonet_amd.ZERO_SHOT)
+        self.augment_pitch = bool(promonet_amd.AUGMENT_PITCH)
+        self.augment_loudness = bool(promonet_amd.AUGMENT_LOUDNESS)
+        self.sparse_method = promonet_amd.SPARSE_PPG_METHOD
+        if self.sparse_method not in _lib.SPARSE_METHODS:
             raise ValueError(
-                'only the default global features (speaker + 2 ratios) are '
-                'supported')
-
-        # generator.py:35-42, 92-95: torch.nn.Embedding default init N(0, 1)
-        self.speaker_embedding = torch.nn.Embedding(
-            promonet_amd.NUM_SPEAKERS, promonet_amd.SPEAKER_CHANNELS)
+                f'Sparsify method {self.sparse_method} is not defined')
+        if self.zero_shot:
+            self.speaker_embedding = torch.nn.Linear(
+                promonet_amd.WAVLM_EMBEDDING_CHANNELS,
+                promonet_amd.SPEAKER_CHANNELS)
+        else:
+            self.speaker_embedding = torch.nn.Embedding(
+                promonet_amd.NUM_SPEAKERS, promonet_amd.SPEAKER_CHANNELS)
         self.pitch_embedding = torch.nn.Embedding(
             promonet_amd.PITCH_BINS, promonet_amd.PITCH_EMBEDDING_SIZE)
         for parameter in self.parameters():
@@ -48,9 +54,11 @@ class Generator(torch.nn.Module):
         self.register_buffer(
             'default_previous_samples',
             torch.zeros(1, 1, promonet_amd.NUM_PREVIOUS_SAMPLES))
-        self.register_buffer(
-            'ppg_threshold',
-            torch.tensor(promonet_amd.SPARSE_PPG_THRESHOLD, dtype=torch.float))
+        if self.sparse_method is not None:               # generator.py:97-104
+            self.register_buffer(
+                'ppg_threshold',
+                torch.tensor(
+                    promonet_amd.SPARSE_PPG_THRESHOLD, dtype=torch.float))
         self.register_buffer(
             'pitch_distribution', promonet_amd.load.pitch_distribution())
 
@@ -134,6 +142,7 @@ class Generator(torch.nn.Module):
                 out_cl, batch, frames, rows, channels,
                 promonet_amd.PITCH_BINS, promonet_amd.PITCH_EMBEDDING_SIZE,
                 promonet_amd.LOUDNESS_BANDS, cpad,
+                _lib.SPARSE_METHODS[self.sparse_method],
                 self._host_threshold(),
                 promonet_amd.FMIN, promonet_amd.FMAX, promonet_amd.MIN_DB,
                 promonet_amd.REF_DB,
@@ -142,6 +151,8 @@ class Generator(torch.nn.Module):
         return out
 
     def _host_threshold(self):
+        if self.sparse_method is None:
+            return 0.
         if self._threshold is None:
             self._threshold = float(np.float32(self.ppg_threshold.item()))
         return self._threshold
@@ -152,26 +163,48 @@ class Generator(torch.nn.Module):
         spectral_balance_ratios,
         loudness_ratios
     ):
-        """(B, 258, 1) global conditioning (generator.py:49-70)."""
+        """(B, 258, 1) global conditioning (generator.py:49-70). `speakers`
+        is (B,) integer ids, or with ZERO_SHOT (B, 512) WavLM x-vectors."""
         lib = _lib.lib()
         _lib.require_gpu(speakers)
-        speakers = speakers.to(torch.long).contiguous()
         batch = speakers.shape[0]
         device = speakers.device
-        sbr = spectral_balance_ratios.to(
-            device=device, dtype=torch.float32).contiguous()
-        lr = loudness_ratios.to(device=device, dtype=torch.float32).contiguous()
-        if sbr.shape != (batch,) or lr.shape != (batch,):
-            raise ValueError('ratios must have shape (B,)')
-        table = self.speaker_embedding.weight.detach().to(
-            torch.float32).contiguous()
-        channels = table.shape[1]
-        out = torch.empty(batch, channels + 2, 1, device=device)
+
+        def ratio(values, used):
+            if not used:
+                return None
+            values = values.to(device=device, dtype=torch.float32).contiguous()
+            if values.shape != (batch,):
+                raise ValueError('ratios must have shape (B,)')
+            return values
+        sbr = ratio(spectral_balance_ratios, self.augment_pitch)
+        lr = ratio(loudness_ratios, self.augment_loudness)
+        channels = promonet_amd.SPEAKER_CHANNELS
+        out = torch.empty(
+            batch, channels + (sbr is not None) + (lr is not None), 1,
+            device=device)
         with torch.cuda.device(device):
-            _lib.check(lib.pm_prepare_global_features(
-                _lib.ptr(speakers, torch.long), _lib.ptr(sbr), _lib.ptr(lr),
-                _lib.ptr(table), _lib.ptr(out), batch, channels,
-                _lib.stream()))
+            if self.zero_shot:
+                speakers = speakers.to(torch.float32).contiguous()
+                weight = self.speaker_embedding.weight.detach().to(
+                    torch.float32).contiguous()
+                bias = self.speaker_embedding.bias.detach().to(
+                    torch.float32).contiguous()
+                if speakers.shape != (batch, weight.shape[1]):
+                    raise ValueError(
+                        f'zero-shot speakers must be (B, {weight.shape[1]})')
+                _lib.check(lib.pm_prepare_global_features_linear(
+                    _lib.ptr(speakers), _lib.ptr(weight), _lib.ptr(bias),
+                    _lib.ptr(sbr), _lib.ptr(lr), _lib.ptr(out), batch,
+                    weight.shape[1], channels, _lib.stream()))
+            else:
+                speakers = speakers.to(torch.long).contiguous()
+                table = self.speaker_embedding.weight.detach().to(
+                    torch.float32).contiguous()
+                _lib.check(lib.pm_prepare_global_features(
+                    _lib.ptr(speakers, torch.long), _lib.ptr(sbr),
+                    _lib.ptr(lr), _lib.ptr(table), _lib.ptr(out), batch,
+                    channels, table.shape[0], _lib.stream()))
         return out
 
     ###########################################################################

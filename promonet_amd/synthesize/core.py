@@ -114,10 +114,17 @@ def from_features_batched(
         return torch.full((batch,), value, dtype=dtype, device=device)
 
     model = _cached_model(checkpoint, device)
+    if model.zero_shot:
+        speakers = speakers.to(device=device, dtype=torch.float)
+        speakers = speakers.reshape(-1, speakers.shape[-1]).expand(
+            batch, -1).contiguous()
+    else:
+        _check_speakers(speakers)
+        speakers = per_item(speakers, torch.long)
     with timer.context('generate'), torch.inference_mode():
         return model(
             loudness.to(device), pitch.to(device), periodicity.to(device),
-            ppg.to(device), per_item(speakers, torch.long),
+            ppg.to(device), speakers,
             per_item(spectral_balance_ratios, torch.float),
             per_item(loudness_ratios, torch.float),
             model.default_previous_samples, lengths)
@@ -275,8 +282,13 @@ def generate(
     model = _cached_model(checkpoint, device)
 
     with timer.context('generate'):
-        speakers = torch.full(
-            (1,), speaker, dtype=torch.long, device=device)
+        if model.zero_shot:                 # core.py:253-254: an x-vector
+            speakers = speaker.to(device=device, dtype=torch.float).reshape(
+                1, -1)
+        else:
+            _check_speakers(speaker)
+            speakers = torch.full(
+                (1,), int(speaker), dtype=torch.long, device=device)
         spectral_balance_ratio = torch.tensor(
             [spectral_balance_ratio], dtype=torch.float, device=device)
         loudness_ratio = torch.tensor(
@@ -285,7 +297,8 @@ def generate(
         if batch > 1:
             # The reference broadcasts one speaker over the batch through the
             # (1, 512, 1) speaker-conv output (hifigan.py:68)
-            speakers = speakers.expand(batch).contiguous()
+            speakers = speakers.expand(
+                batch, *speakers.shape[1:]).contiguous()
             spectral_balance_ratio = \
                 spectral_balance_ratio.expand(batch).contiguous()
             loudness_ratio = loudness_ratio.expand(batch).contiguous()
@@ -305,6 +318,25 @@ def generate(
 ###############################################################################
 # Utilities
 ###############################################################################
+
+
+def _check_speakers(speakers):
+    """Host-side ids (ints, lists, CPU tensors) are validated like the
+    reference's torch.nn.Embedding does (IndexError); device tensors are not
+    read back (no sync) - the kernel turns an out-of-range id into NaN audio."""
+    if isinstance(speakers, torch.Tensor):
+        if speakers.is_cuda:
+            return
+        values = speakers.reshape(-1).tolist()
+    elif isinstance(speakers, (list, tuple)):
+        values = list(speakers)
+    else:
+        values = [speakers]
+    for value in values:
+        if not 0 <= int(value) < promonet_amd.NUM_SPEAKERS:
+            raise IndexError(
+                f'speaker {int(value)} is out of range '
+                f'[0, {promonet_amd.NUM_SPEAKERS})')
 
 
 def _device(gpu, like=None):

@@ -1,10 +1,12 @@
 #!/bin/bash
 # On the GPU box: interleaved A/B of environment settings, 3 rounds each.
+# The switches exist in a tuning build only: scripts/build_variant.sh tuning -DPM_TUNING,
+# then PROMONET_HIP_LIB=.../libpromonet_hip_tuning.so.
 # usage: [AB_FILTER=substr] scripts/ab_env.sh "PM_FUSION=block" "PM_FUSION=mrf" ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for round in 1 2 3; do
   for v in "$@"; do
-    env $v python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | AB_FILTER=$AB_FILTER python -c "
+    env $v python $ROOT/bench.py --steps 6 --warmup 2 --sustain 0 --no-cpu-baseline 2>/dev/null | AB_FILTER=$AB_FILTER python -c "
 import json,sys,os; r=json.loads(sys.stdin.read()); k=r['kernels']; f=os.environ.get('AB_FILTER','')
 print('[$v] round $round: %.2f ms | ' % r['ms_per_step'] + ' '.join('%s %.3f' % (n.replace('block_','b').replace('pair_','p'), v['ms_per_step']) for n, v in sorted(k.items()) if (f in n if f else v['ms_per_step'] > 0.6)))"
   done

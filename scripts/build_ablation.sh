@@ -7,7 +7,7 @@ set -e
 cd $(dirname $0)/..
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-value -fno-honor-nans"
 for v in A B AB; do
-  D=""; [[ $v == *A* ]] && D="$D -DPM_ABLATE_A"; [[ $v == *B* ]] && D="$D -DPM_ABLATE_B"
+  D="-DPM_TUNING"; [[ $v == *A* ]] && D="$D -DPM_ABLATE_A"; [[ $v == *B* ]] && D="$D -DPM_ABLATE_B"
   /opt/rocm/bin/hipcc $F $D -c promonet_amd/csrc/pm_conv_f16.hip -o build/obj/pm_conv_f16_no$v.o &
 done
 wait

@@ -26,6 +26,28 @@ def stand_in(loudness, pitch, periodicity, ppg, speakers, sbr, lr):
     return frame.repeat_interleave(256, dim=-1)[:, None]
 
 
+class FakeEngineOwner(torch.nn.Module):
+    """Stands for HiFiGAN / FARGAN: owns a packed engine built from its
+    parameters (here: a flag) that an in-place update must invalidate."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.rand(3))
+        self.packed = True
+
+    def _invalidate(self):
+        self.packed = False
+
+
+class FakeGenerator(torch.nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.model = torch.nn.Sequential(FakeEngineOwner())   # bare container
+        self.register_buffer('ppg_threshold', torch.rand(()))
+        self._threshold = 0.5
+
+
 def worker(rank, world, port, total, results):
     os.environ.update(
         RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
@@ -45,6 +67,12 @@ def worker(rank, world, port, total, results):
     want.register_buffer('edges', torch.rand(6))
     for a, b in zip(model.state_dict().values(), want.state_dict().values()):
         assert torch.equal(a, b)
+
+    # engines packed before the broadcast are dropped on every rank, however
+    # deep they sit, and host copies of buffers are reset
+    fake = FakeGenerator()
+    distributed.broadcast_model(fake)
+    assert fake.model[0].packed is False and fake._threshold is None
 
     # sharded synthesis + all-gather (uneven shards when total % world != 0)
     gen = torch.Generator().manual_seed(5)
@@ -90,6 +118,13 @@ def test_world_size_2_even():
 
 def test_world_size_2_uneven():
     run(total=5)
+
+
+def test_world_size_2_fewer_utterances_than_ranks():
+    """One utterance, two ranks: rank 1 owns an empty shard, must not call the
+    synthesis function (the engine rejects B = 0) and still joins the
+    all-gather - the job used to hang here."""
+    run(total=1)
 
 
 def test_shard_bounds_cover_the_batch():

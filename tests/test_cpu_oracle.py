@@ -174,3 +174,53 @@ def test_edit_golden(golden_default):
         sample['sequence'], sample['grid']), sample['linear']) < 1e-6
     assert max_abs(oracle.grid_sample(
         sample['sequence'], sample['grid'], 'nearest'), sample['nearest']) == 0.
+
+
+@pytest.mark.parametrize('which', ['zero_shot', 'sparse_none'])
+def test_conditioning_variants(which):
+    """ZERO_SHOT / SPARSE_PPG_METHOD = None goldens (real reference,
+    oracle/make_golden.py) against the restatement."""
+    from conftest import GOLDEN
+    g = torch.load(GOLDEN / f'variant_{which}.pt', weights_only=False)
+    state = g['state']
+    with torch.inference_mode():
+        features = oracle.prepare_features(
+            *g['inputs'][:4], state['pitch_distribution'],
+            state['pitch_embedding.weight'], state.get('ppg_threshold', 0.),
+            g['config']['SPARSE_PPG_METHOD'])
+        glob = oracle.prepare_global_features(
+            *g['inputs'][4:7], state['speaker_embedding.weight'],
+            state.get('speaker_embedding.bias'))
+        audio = oracle.hifigan_forward(features, glob, state)
+    assert max_abs(features, g['features']) < 1e-6
+    assert max_abs(glob, g['global_features']) < 1e-6
+    assert max_abs(audio, g['audio']) < 1e-6
+
+
+def test_sparsify_second_source():
+    """ppgs.sparsify is unpinned (package absent): second-source the quantile
+    against numpy's default 'linear' method, ties included, and check the
+    topk / constant variants against direct definitions."""
+    import numpy as np
+    gen = torch.Generator().manual_seed(4)
+    ppg = torch.softmax(3. * torch.randn(3, 40, 50, generator=gen), dim=1)
+    ppg[0, :, 7] = 1. / 40
+    ppg[1, 10:20, 8] = ppg[1, 20:30, 8]
+    for q in (.85, .5, 0., 1., .33):
+        mine = torch.quantile(ppg, q, dim=-2, keepdim=True)
+        theirs = np.quantile(ppg.double().numpy(), q, axis=-2, keepdims=True)
+        assert np.abs(mine.numpy() - theirs).max() < 1e-7
+        out = oracle.sparsify(ppg, 'percentile', q)
+        assert torch.allclose(out.sum(-2), torch.ones(3, 50), atol=1e-5)
+        # softmax(log(p + 1e-8)) == (p + 1e-8) / sum(p + 1e-8)
+        masked = torch.where(ppg > mine, ppg, torch.zeros_like(ppg)) + 1e-8
+        direct = masked / masked.sum(-2, keepdim=True)
+        assert torch.allclose(out, direct, rtol=1e-4, atol=1e-12)
+    top = oracle.sparsify(ppg, 'topk', 5)
+    fifth = torch.sort(ppg, dim=-2, descending=True).values[:, 4:5]
+    distinct = ((ppg == fifth).sum(-2) == 1)               # no tie at the cut
+    assert ((top > 1e-7).sum(-2)[distinct] == 5).all()
+    constant = oracle.sparsify(ppg, 'constant', torch.tensor(.05))
+    masked = torch.where(ppg > .05, ppg, torch.zeros_like(ppg)) + 1e-8
+    assert torch.allclose(
+        constant, masked / masked.sum(-2, keepdim=True), rtol=1e-4, atol=1e-12)
