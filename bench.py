@@ -106,47 +106,55 @@ def synthetic_inputs(batch, frames, seed, device):
         loudness, pitch, periodicity, ppg, speakers, ones, ones.clone())]
 
 
-def cpu_baseline(model_name, budget=60.):
+def cpu_baseline(model_name, budget=40.):
     """The CPU oracle (a port of the reference's op sequence in PyTorch fp32)
-    timed on this host's cores: BASELINE.json config 2's shape (batch 8 x 5 s;
-    FARGAN: 2 x 1 s), at os.cpu_count() torch threads and at 8, median of up
-    to 3 runs after 1 warm-up, bounded by `budget` seconds of CPU work in all
-    (a reported baseline, not the target)."""
+    timed on this host's cores at os.cpu_count() torch threads and at 8
+    (SURVEY.md section 8(d)): median of 3 runs after a warm-up, on a sample of
+    BASELINE.json config 2's shape (batch 8 x 5 s; FARGAN: batch 2) that a
+    short probe sizes so that each thread setting gets about budget / 2
+    seconds of CPU work - a many-core host with a slow all-core setting then
+    times a smaller batch instead of stalling the bench. A reported baseline,
+    not the target."""
     sys.path.insert(0, str(ROOT / 'oracle'))
     import restatement as oracle
     if model_name == 'fargan':
-        batch, frames = 2, 86
+        full_batch, full_frames, probe_frames = 2, 430, 6
         state = oracle.random_state_fargan(seed=0)
         forward = oracle.fargan_generator_forward
         name = 'fargan_generator_forward'
     else:
-        batch, frames = 8, 430
+        full_batch, full_frames, probe_frames = 8, 430, 43
         state = oracle.random_state(seed=0)
         forward = oracle.generator_forward
         name = 'generator_forward'
-    inputs = oracle.synthetic_inputs(batch, frames, seed=1234)
-    samples = batch * frames * promonet_amd.HOPSIZE
+    hop = promonet_amd.HOPSIZE
     cpus = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    by_threads, runs_by_threads = {}, {}
     settings = sorted({cpus, min(8, cpus)}, reverse=True)
+    slot = budget / len(settings)
+
+    def run(batch, frames):
+        inputs = oracle.synthetic_inputs(batch, frames, seed=1234)
+        start = time.perf_counter()
+        forward(*inputs, state)
+        return time.perf_counter() - start
+
+    by_threads, sample_by_threads = {}, {}
     spent = 0.
     with torch.inference_mode():
         for threads in settings:
             torch.set_num_threads(threads)
-            allotted = budget / len(settings)
-            start = time.perf_counter()
-            forward(*inputs, state)                         # warm-up
-            used = time.perf_counter() - start
-            times = []
-            while len(times) < 3 and (not times or used + times[-1] < allotted):
-                start = time.perf_counter()
-                forward(*inputs, state)
-                times.append(time.perf_counter() - start)
-                used += times[-1]
-            spent += used
-            by_threads[threads] = samples / statistics.median(times)
-            runs_by_threads[threads] = len(times)
+            begin = time.perf_counter()
+            run(1, probe_frames)                                  # warm-up
+            rate = probe_frames * hop / run(1, probe_frames)      # probe
+            # largest (batch, frames) <= config 2's whose 3 runs fit the slot
+            affordable = rate * slot / 3.5 / hop                  # frames
+            batch = int(min(full_batch, max(1, affordable // full_frames)))
+            frames = int(min(full_frames, max(probe_frames, affordable // batch)))
+            times = [run(batch, frames) for _ in range(3)]
+            by_threads[threads] = batch * frames * hop / statistics.median(times)
+            sample_by_threads[threads] = f'{batch} x {frames} frames'
+            spent += time.perf_counter() - begin
     torch.set_num_threads(default_threads)
     threads = max(by_threads, key=by_threads.get)
     return {
@@ -154,12 +162,14 @@ def cpu_baseline(model_name, budget=60.):
         'kind': 'port',
         'rtf': by_threads[threads] / promonet_amd.SAMPLE_RATE,
         'samples_per_s_by_threads': by_threads,
-        'timed_runs_by_threads': runs_by_threads,
+        'sample_by_threads': sample_by_threads,
         'sample': f'oracle/restatement.py {name} (PyTorch CPU port of the '
-                  f'reference op sequence), fp32, batch {batch} x {frames} '
-                  f'frames, median of the timed runs after 1 warm-up at '
-                  f'{sorted(by_threads)} torch threads on {cpus} cpus '
-                  f'({spent:.0f} s of CPU work); value = the faster setting'}
+                  f'reference op sequence), fp32, median of 3 runs after a '
+                  f'warm-up at {sorted(by_threads)} torch threads on {cpus} '
+                  f'cpus, batch x frames per setting sized by a probe to '
+                  f'~{slot:.0f} s each ({sample_by_threads}; config 2 is '
+                  f'{full_batch} x {full_frames}); {spent:.0f} s of CPU work; '
+                  f'value = the faster setting'}
 
 
 def parse_profile(text):
@@ -389,17 +399,21 @@ def main():
             avg_ms = row['ms'] / row['launches']
             flops_per_launch = row['flops'] / row['launches']
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            traffic, measured_step_bytes = None, None
+            traffic, measured_step_bytes, covered_ms = None, None, 0.
             traffic_file = ROOT / 'profiles' / 'traffic.json'
             if traffic_file.exists() and args.batch == 32 and frames == 861:
                 table = json.loads(traffic_file.read_text())
                 traffic = table.get(f'{label}:{args.dtype}')
-                per_step = [
-                    table.get(f'{k}:{args.dtype}') for k in profile]
-                if all(v is not None for v in per_step):
-                    measured_step_bytes = sum(
-                        v * profile[k]['launches'] / args.steps
-                        for k, v in zip(profile, per_step))
+                measured_step_bytes = 0.
+                for key, entry in profile.items():
+                    nbytes = table.get(f'{key}:{args.dtype}')
+                    if nbytes is None:
+                        # no PMC pass for this kernel: its algorithmic bytes
+                        nbytes = entry['bytes'] / entry['launches']
+                    else:
+                        covered_ms += entry['ms']
+                    measured_step_bytes += \
+                        nbytes * entry['launches'] / args.steps
             kernel_ms = sum(r['ms'] for r in profile.values()) / args.steps
             result['roofline'] = {
                 'kernel': label,
@@ -434,6 +448,9 @@ def main():
                 'measured_frac_of_hbm_peak': (
                     measured_step_bytes / (elapsed / args.steps) / 1e9 /
                     PEAK_HBM_GBS if measured_step_bytes else None),
+                'pmc_covered_share_of_kernel_time': (
+                    covered_ms / sum(r['ms'] for r in profile.values())
+                    if measured_step_bytes else None),
                 # a MODEL, not a measurement: the bytes an unfused
                 # layer-by-layer implementation would move
                 # at this step time; the fused kernels move far fewer

@@ -278,6 +278,21 @@ int pm_stft_magnitude(const float* audio, float* out, int batch, int samples,
 int pm_linear_to_mel(const float* spec, const float* basis, float* out,
                      int batch, int bins, int mels, int frames,
                      int use_threshold, float log_threshold, void* stream);
+/* Backward passes of the two functions above, for the training-side mel loss
+ * that differentiates through spectrogram.from_audio(generated, True)
+ * (promonet/train/core.py:277-305): grad_out (B, 513, N / 256) ->
+ * grad_audio (B, N); grad_mel (B, Mel, T) -> grad_spec (B, F, T), `scratch`
+ * = batch * mels * frames floats.                                          */
+size_t pm_stft_backward_scratch_bytes(int batch, int samples);
+int pm_stft_magnitude_backward(const float* audio, const float* grad_out,
+                               float* grad_audio, int batch, int samples,
+                               void* scratch, size_t scratch_bytes,
+                               void* stream);
+int pm_linear_to_mel_backward(const float* spec, const float* basis,
+                              const float* grad_mel, float* grad_spec,
+                              float* scratch, int batch, int bins, int mels,
+                              int frames, int use_threshold,
+                              float log_threshold, void* stream);
 /* loudness.from_audio (loudness.py:17-55) per utterance: A-weighted dB with
  * the utterance-global (max - 80 dB) floor of librosa.amplitude_to_db, then
  * band_average (loudness.py:84-111): audio (B, N) -> (B, bands, N / 256);

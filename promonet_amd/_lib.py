@@ -79,6 +79,9 @@ SIGNATURES = {
     'pm_stft_scratch_bytes': (_S, [_I, _I]),
     'pm_stft_magnitude': (_I, [_P, _P, _I, _I, _P, _S, _P]),
     'pm_linear_to_mel': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    'pm_stft_backward_scratch_bytes': (_S, [_I, _I]),
+    'pm_stft_magnitude_backward': (_I, [_P, _P, _P, _I, _I, _P, _S, _P]),
+    'pm_linear_to_mel_backward': (_I, [_P] * 5 + [_I] * 5 + [_F, _P]),
     'pm_loudness_scratch_bytes': (_S, [_I, _I]),
     'pm_loudness': (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _S, _P]),
 }

@@ -171,7 +171,12 @@ struct ConvGeom {
     int M = 0;               // packed rows (cout_pad, or r * cout_pad)
     int ch = 64, kt = 0;
     int r = 0, p = 0;
-    size_t packed_elems() const { return (size_t)M * cin_pad * kt; }
+    bool bias_step = false;  // MRF convs: the stream of every M tile ends
+                             // with one bias step (pm_pack_bias_step_kernel)
+    size_t weight_elems() const { return (size_t)M * cin_pad * kt; }
+    size_t packed_elems() const {
+        return weight_elems() + (bias_step ? (size_t)(M / 32) * 512 : 0);
+    }
 };
 
 static hipError_t pack_weights(
@@ -182,8 +187,34 @@ static hipError_t pack_weights(
     a.cout_pad = g.cout_pad; a.cin_pad = g.cin_pad;
     a.mtiles = g.M / 32; a.nch = g.cin_pad / g.ch; a.ch = g.ch; a.kt = g.kt;
     a.r = g.r; a.p = g.p;
-    a.total = (long long)g.packed_elems();
+    a.bias_step = g.bias_step ? 1 : 0;
+    a.total = (long long)g.weight_elems();
     return launch_pack(dtype, a, s);
+}
+
+// Write the bias step of every M tile of a packed MRF conv stream
+static hipError_t pack_bias_step(
+    int dtype, const ConvGeom& g, const float* bias, void* out, hipStream_t s) {
+    const int mtiles = g.M / 32;
+    const long long per_mt = (long long)g.weight_elems() / mtiles;
+    const dim3 grid((mtiles * 512 + 255) / 256), block(256);
+    switch (dtype) {
+        case PM_F32:
+            hipLaunchKernelGGL(pm_pack_bias_step_kernel<ElemF32>, grid, block,
+                               0, s, bias, out, g.cout, mtiles, per_mt);
+            break;
+        case PM_F16:
+            hipLaunchKernelGGL(pm_pack_bias_step_kernel<ElemF16>, grid, block,
+                               0, s, bias, out, g.cout, mtiles, per_mt);
+            break;
+        case PM_BF16:
+            hipLaunchKernelGGL(pm_pack_bias_step_kernel<ElemBF16>, grid, block,
+                               0, s, bias, out, g.cout, mtiles, per_mt);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 static hipError_t pad_bias(
@@ -206,7 +237,7 @@ static int single_cfg(int M, int ch, int wave64_ok) {
 // ---------------------------------------------------------------------------
 struct Layer {
     ConvGeom geom;
-    void* w = nullptr;        // packed
+    void* w = nullptr;        // packed (+ bias steps for MRF convs)
     float* bias = nullptr;    // padded (tiled per phase for conv-transpose)
     float* tmp_g = nullptr;   // weight-norm pair awaiting its partner
     float* tmp_v = nullptr;
@@ -348,6 +379,7 @@ extern "C" int pm_hifigan_create(
                     q.cout_pad = q.cin_pad = q.M = s.cout_pad;
                     q.kt = q.k;
                     q.ch = mrf_chunk(h->dtype, s.cout_pad, q.k, c->num_dilations);
+                    q.bias_step = true;
                 }
     }
     {
@@ -413,12 +445,14 @@ static int set_weight(
     if (!l.w) HIP_TRY(hipMalloc(&l.w, bytes));
     HIP_TRY(pack_weights(h->dtype, g, w, l.w, s));
     l.has_w = true;
+    if (g.bias_step && l.has_b)
+        HIP_TRY(pack_bias_step(h->dtype, g, l.bias, l.w, s));
     return PM_OK;
 }
 
 static int set_bias(
-    Layer& l, const float* b, const int64_t* shape, int ndim, hipStream_t s,
-    const char* name) {
+    pm_hifigan_t h, Layer& l, const float* b, const int64_t* shape, int ndim,
+    hipStream_t s, const char* name) {
     const ConvGeom& g = l.geom;
     if (ndim != 1 || shape[0] != g.cout)
         return fail(PM_EINVAL, "%s: expected shape (%d)", name, g.cout);
@@ -428,6 +462,8 @@ static int set_bias(
                           (size_t)g.cout_pad * rep * sizeof(float)));
     HIP_TRY(pad_bias(b, l.bias, g.cout, g.cout_pad, rep, s));
     l.has_b = true;
+    if (g.bias_step && l.has_w)
+        HIP_TRY(pack_bias_step(h->dtype, g, l.bias, l.w, s));
     return PM_OK;
 }
 
@@ -472,7 +508,7 @@ static int set_layer_tensor(
     pm_hifigan_t h, Layer& l, const char* leaf, const float* t,
     const int64_t* shape, int ndim, hipStream_t s, const char* name) {
     if (!strcmp(leaf, "weight")) return set_weight(h, l, t, shape, ndim, s, name);
-    if (!strcmp(leaf, "bias")) return set_bias(l, t, shape, ndim, s, name);
+    if (!strcmp(leaf, "bias")) return set_bias(h, l, t, shape, ndim, s, name);
     if (!strcmp(leaf, "weight_g"))
         return set_norm_part(h, l, true, t, shape, ndim, s, name);
     if (!strcmp(leaf, "weight_v"))
@@ -681,8 +717,8 @@ static int forward_impl(
                 a.x = buf[ui]; a.out = buf[si];
                 a.niter = h->cfg.num_dilations;
                 for (int n = 0; n < a.niter; ++n) {
-                    a.w1[n] = st.c1[j][n].w; a.b1[n] = st.c1[j][n].bias;
-                    a.w2[n] = st.c2[j][n].w; a.b2[n] = st.c2[j][n].bias;
+                    a.w1[n] = st.c1[j][n].w;
+                    a.w2[n] = st.c2[j][n].w;
                     a.dil[n] = h->cfg.resblock_dilations[j][n];
                     flops += 4.0 * st.cout * st.cout *
                              h->cfg.resblock_kernel_sizes[j] * B * L;
@@ -711,8 +747,8 @@ static int forward_impl(
                 a.niter = h->cfg.num_dilations;
                 double flops = 0;
                 for (int n = 0; n < a.niter; ++n) {
-                    a.w1[n] = st.c1[j][n].w; a.b1[n] = st.c1[j][n].bias;
-                    a.w2[n] = st.c2[j][n].w; a.b2[n] = st.c2[j][n].bias;
+                    a.w1[n] = st.c1[j][n].w;
+                    a.w2[n] = st.c2[j][n].w;
                     a.dil[n] = h->cfg.resblock_dilations[j][n];
                     flops += 4.0 * st.cout * st.cout * K * B * L;
                 }
@@ -736,8 +772,8 @@ static int forward_impl(
                 float* dst = last ? buf[si] : ((n & 1) ? buf[bi] : buf[ai]);
                 PairArgs a = {};
                 a.x = src; a.out = dst;
-                a.w1 = st.c1[j][n].w; a.b1 = st.c1[j][n].bias;
-                a.w2 = st.c2[j][n].w; a.b2 = st.c2[j][n].bias;
+                a.w1 = st.c1[j][n].w;
+                a.w2 = st.c2[j][n].w;
                 a.B = B; a.L = L;
                 a.dilation = h->cfg.resblock_dilations[j][n];
                 a.mode = last ? (j == 0 ? 1 : 2) : 0;
@@ -943,7 +979,9 @@ extern "C" int pm_prepare_global_features_linear(
 // ---------------------------------------------------------------------------
 extern "C" size_t pm_op_workspace_bytes(int c_in, int c_out, int k) {
     const size_t ci = pad32(c_in), co = pad32(c_out);
-    return 2 * align256(ci * co * (size_t)k * 4) + 2 * align256(co * 64 * 4);
+    // two packed weight streams (fp32-sized, + bias steps) and two padded biases
+    return 2 * align256((ci * co * (size_t)k + co * 16) * 4) +
+           2 * align256(co * 64 * 4);
 }
 
 extern "C" int pm_block_iteration_cl(
@@ -962,9 +1000,9 @@ extern "C" int pm_block_iteration_cl(
     hipStream_t s = (hipStream_t)stream;
     ConvGeom g;
     g.mode = 0; g.cout = g.cin = C; g.k = K; g.cout_pad = g.cin_pad = g.M = Cp;
-    g.kt = K; g.ch = pair_chunk(dtype, Cp);
+    g.kt = K; g.ch = pair_chunk(dtype, Cp); g.bias_step = true;
     char* base = (char*)ws;
-    const size_t wsz = align256((size_t)Cp * Cp * K * 4);
+    const size_t wsz = align256(((size_t)Cp * Cp * K + Cp * 16) * 4);
     void* p1 = base; void* p2 = base + wsz;
     float* pb1 = (float*)(base + 2 * wsz);
     float* pb2 = pb1 + align256(Cp * 64 * 4) / 4;
@@ -972,8 +1010,10 @@ extern "C" int pm_block_iteration_cl(
     HIP_TRY(pack_weights(dtype, g, w2, p2, s));
     HIP_TRY(pad_bias(b1, pb1, C, Cp, 1, s));
     HIP_TRY(pad_bias(b2, pb2, C, Cp, 1, s));
+    HIP_TRY(pack_bias_step(dtype, g, pb1, p1, s));
+    HIP_TRY(pack_bias_step(dtype, g, pb2, p2, s));
     PairArgs a = {};
-    a.x = x; a.out = out; a.w1 = p1; a.w2 = p2; a.b1 = pb1; a.b2 = pb2;
+    a.x = x; a.out = out; a.w1 = p1; a.w2 = p2;
     a.B = B; a.L = L; a.dilation = d; a.mode = mode; a.scale = scale;
     HIP_TRY(launch_pair(dtype, Cp, K, a, s));
     return PM_OK;
@@ -1010,12 +1050,12 @@ extern "C" int pm_block_cl(
     hipStream_t s = (hipStream_t)stream;
     ConvGeom g;
     g.mode = 0; g.cout = g.cin = C; g.k = K; g.cout_pad = g.cin_pad = g.M = Cp;
-    g.kt = K; g.ch = Cp < 64 ? Cp : 64;
+    g.kt = K; g.ch = Cp < 64 ? Cp : 64; g.bias_step = true;
     Block3Args a = {};
     a.x = x; a.out = out; a.niter = niter; a.B = B; a.L = L; a.mode = mode;
     a.scale = scale;
     const size_t per = pm_op_workspace_bytes(C, C, K);
-    const size_t wsz = align256((size_t)Cp * Cp * K * 4);
+    const size_t wsz = align256(((size_t)Cp * Cp * K + Cp * 16) * 4);
     for (int n = 0; n < niter; ++n) {
         char* base = (char*)ws + n * per;
         void* p1 = base; void* p2 = base + wsz;
@@ -1025,7 +1065,9 @@ extern "C" int pm_block_cl(
         HIP_TRY(pack_weights(dtype, g, w2[n], p2, s));
         HIP_TRY(pad_bias(b1[n], pb1, C, Cp, 1, s));
         HIP_TRY(pad_bias(b2[n], pb2, C, Cp, 1, s));
-        a.w1[n] = p1; a.w2[n] = p2; a.b1[n] = pb1; a.b2[n] = pb2;
+        HIP_TRY(pack_bias_step(dtype, g, pb1, p1, s));
+        HIP_TRY(pack_bias_step(dtype, g, pb2, p2, s));
+        a.w1[n] = p1; a.w2[n] = p2;
         a.dil[n] = dilations[n];
     }
     hipError_t e = launch_block3(dtype, Cp, K, a, s);
@@ -1107,19 +1149,30 @@ extern "C" int pm_to_channels_last(
 static const int NFFT = 1024, HOP = 256, BINS = 513, DFT_M = 1088;
 
 static std::mutex g_basis_mutex;
-static std::map<int, void*> g_basis;   // per device: packed windowed DFT basis
+struct DftBasis {
+    void* forward = nullptr;     // packed windowed DFT basis (1088 x 256 x 4)
+    void* backward = nullptr;    // packed transposed basis (256 x 1088 x 4)
+    float* zeros = nullptr;      // 256 zero biases for the backward conv
+};
+static std::map<int, DftBasis> g_basis;   // per device
 
-static int get_dft_basis(void** out, hipStream_t s) {
+static int get_dft_basis(DftBasis* out, hipStream_t s) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_basis_mutex);
     auto it = g_basis.find(dev);
     if (it != g_basis.end()) { *out = it->second; return PM_OK; }
     float* raw = nullptr;
-    void* packed = nullptr;
+    float* rawt = nullptr;
+    DftBasis basis;
     const size_t raw_elems = 2ull * BINS * NFFT;
+    const size_t packed_bytes = (size_t)DFT_M * NFFT * sizeof(float);
     HIP_TRY(hipMalloc((void**)&raw, raw_elems * sizeof(float)));
-    HIP_TRY(hipMalloc(&packed, (size_t)DFT_M * NFFT * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&rawt, packed_bytes));
+    HIP_TRY(hipMalloc(&basis.forward, packed_bytes));
+    HIP_TRY(hipMalloc(&basis.backward, packed_bytes));
+    HIP_TRY(hipMalloc((void**)&basis.zeros, HOP * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(basis.zeros, 0, HOP * sizeof(float), s));
     hipLaunchKernelGGL(pm_dft_basis_kernel,
                        dim3((unsigned)((raw_elems + 255) / 256)), dim3(256), 0,
                        s, raw, BINS, NFFT, HOP);
@@ -1127,11 +1180,22 @@ static int get_dft_basis(void** out, hipStream_t s) {
     ConvGeom g;
     g.mode = 0; g.cout = 2 * BINS; g.cin = HOP; g.k = NFFT / HOP;
     g.cout_pad = g.M = DFT_M; g.cin_pad = HOP; g.kt = g.k; g.ch = 64;
-    HIP_TRY(pack_weights(PM_F32, g, raw, packed, s));
+    HIP_TRY(pack_weights(PM_F32, g, raw, basis.forward, s));
+    // backward: out[q][c] = sum_j sum_m G[q - 3 + j][m] wt[c][m][j]
+    const size_t t_elems = (size_t)HOP * DFT_M * (NFFT / HOP);
+    hipLaunchKernelGGL(pm_dft_basis_transpose_kernel,
+                       dim3((unsigned)((t_elems + 255) / 256)), dim3(256), 0,
+                       s, raw, rawt, 2 * BINS, DFT_M, HOP, NFFT / HOP);
+    HIP_TRY(hipGetLastError());
+    ConvGeom gt;
+    gt.mode = 0; gt.cout = HOP; gt.cin = DFT_M; gt.k = NFFT / HOP;
+    gt.cout_pad = gt.M = HOP; gt.cin_pad = DFT_M; gt.kt = gt.k; gt.ch = 64;
+    HIP_TRY(pack_weights(PM_F32, gt, rawt, basis.backward, s));
     HIP_TRY(hipStreamSynchronize(s));
     hipFree(raw);
-    g_basis[dev] = packed;
-    *out = packed;
+    hipFree(rawt);
+    g_basis[dev] = basis;
+    *out = basis;
     return PM_OK;
 }
 
@@ -1143,7 +1207,8 @@ extern "C" size_t pm_stft_scratch_bytes(int B, int N) {
 
 static int stft_launch(
     int epi, const float* audio, float* out, unsigned* maxbits, int B, int N,
-    void* scratch, size_t scratch_bytes, hipStream_t s) {
+    void* scratch, size_t scratch_bytes, hipStream_t s,
+    const float* grad = nullptr) {
     if (!audio || !out || !scratch) return fail(PM_EINVAL, "null argument");
     const int pad = (NFFT - HOP) / 2;
     if (B < 1 || N <= pad)
@@ -1152,7 +1217,7 @@ static int stft_launch(
     if (T < 1) return fail(PM_EINVAL, "fewer samples than one hop");
     if (scratch_bytes < pm_stft_scratch_bytes(B, N))
         return fail(PM_ENOMEM, "scratch too small");
-    void* basis = nullptr;
+    DftBasis basis;
     int rc = get_dft_basis(&basis, s);
     if (rc) return rc;
     float* padded = (float*)scratch;
@@ -1162,10 +1227,10 @@ static int stft_launch(
                        dim3(256), 0, s, audio, padded, N, pad, Np);
     HIP_TRY(hipGetLastError());
     SingleArgs a = {};
-    a.x = padded; a.out = out; a.w = basis; a.bias = nullptr;
+    a.x = padded; a.out = out; a.w = basis.forward; a.bias = nullptr;
     a.gbias = nullptr; a.gbias_batch = 1;
     a.B = B; a.L = T + 3; a.Lout = T; a.Cin = HOP; a.M = DFT_M;
-    a.bins = BINS; a.maxbits = maxbits; a.lrelu = 0; a.pad = 0;
+    a.bins = BINS; a.maxbits = maxbits; a.grad = grad; a.lrelu = 0; a.pad = 0;
     a.phase_r = 0; a.phase_c = 1;
     HIP_TRY(pm_launch_stft(epi, a, s));
     return PM_OK;
@@ -1176,6 +1241,75 @@ extern "C" int pm_stft_magnitude(
     size_t scratch_bytes, void* stream) {
     return stft_launch(1, audio, out, nullptr, B, N, scratch, scratch_bytes,
                        (hipStream_t)stream);
+}
+
+// Backward of pm_stft_magnitude (the training mel loss differentiates through
+// spectrogram.from_audio: promonet/train/core.py:277-305). Two exact-fp32 MFMA
+// convs: the framed DFT again, its epilogue turning the incoming gradient into
+// the DFT cotangent grad / |X| * (re, im); then the overlap-add of that
+// cotangent against the transposed basis; then the adjoint of the reflect pad.
+extern "C" size_t pm_stft_backward_scratch_bytes(int B, int N) {
+    if (B < 1 || N < HOP) return 0;
+    const size_t T = N / HOP;
+    return pm_stft_scratch_bytes(B, N) +
+           align256((size_t)B * T * DFT_M * sizeof(float)) +
+           align256((size_t)B * (T + 3) * HOP * sizeof(float));
+}
+
+extern "C" int pm_stft_magnitude_backward(
+    const float* audio, const float* grad_out, float* grad_audio, int B, int N,
+    void* scratch, size_t scratch_bytes, void* stream) {
+    if (!audio || !grad_out || !grad_audio || !scratch)
+        return fail(PM_EINVAL, "null argument");
+    if (B < 1 || N < HOP || scratch_bytes < pm_stft_backward_scratch_bytes(B, N))
+        return fail(PM_ENOMEM, "scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = N / HOP;
+    const int pad = (NFFT - HOP) / 2;
+    char* base = (char*)scratch;
+    const size_t stft_bytes = pm_stft_scratch_bytes(B, N);
+    float* cot = (float*)(base + stft_bytes);               // (B, T, 1088)
+    float* gpad = (float*)(base + stft_bytes +
+                           align256((size_t)B * T * DFT_M * sizeof(float)));
+    int rc = stft_launch(3, audio, cot, nullptr, B, N, base, stft_bytes, s,
+                         grad_out);
+    if (rc) return rc;
+    DftBasis basis;
+    rc = get_dft_basis(&basis, s);
+    if (rc) return rc;
+    SingleArgs a = {};
+    a.x = cot; a.out = gpad; a.w = basis.backward; a.bias = basis.zeros;
+    a.gbias = nullptr; a.gbias_batch = 1;
+    a.B = B; a.L = T; a.Lout = T + 3; a.Cin = DFT_M; a.M = HOP;
+    a.lrelu = 0; a.pad = 3; a.phase_r = 0; a.phase_c = 1;
+    HIP_TRY(pm_launch_stft(0, a, s));
+    const int Np = (T + 3) * HOP;
+    hipLaunchKernelGGL(pm_reflect_pad_adjoint_kernel,
+                       dim3((N + 255) / 256, B), dim3(256), 0, s, gpad,
+                       grad_audio, N, pad, Np);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+// Backward of pm_linear_to_mel: grad_mel (B, M, T) -> grad_spec (B, F, T);
+// scratch holds B * M * T floats.
+extern "C" int pm_linear_to_mel_backward(
+    const float* spec, const float* basis, const float* grad_mel,
+    float* grad_spec, float* scratch, int B, int F, int M, int T,
+    int use_threshold, float log_threshold, void* stream) {
+    if (!spec || !basis || !grad_mel || !grad_spec || !scratch)
+        return fail(PM_EINVAL, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pm_mel_backward_rows_kernel,
+                       dim3((T + 255) / 256, M, B), dim3(256), 0, s, spec,
+                       basis, grad_mel, scratch, F, M, T, use_threshold,
+                       log_threshold);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(pm_mel_backward_cols_kernel,
+                       dim3((T + 255) / 256, F, B), dim3(256), 0, s, basis,
+                       scratch, grad_spec, F, M, T);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
 }
 
 extern "C" int pm_linear_to_mel(
@@ -1254,7 +1388,9 @@ struct FLayer {
     const char* leaf;    // leaf of a plain tensor ("weight", "weight_ih", ...)
     bool normed;         // weight-normed Linear: accepts weight_g + weight_v
     int rows, cols, rpad, kpad;
+    int kw = 0;              // > 0: also packed K-split, 8 x (rpad x kw)
     void* packed = nullptr;
+    void* packed_k = nullptr;
     float* tmp_g = nullptr;
     float* tmp_v = nullptr;
     bool has = false;
@@ -1289,6 +1425,11 @@ static std::vector<FLayer> fargan_layers(int nin) {
         {FG_P "skip_glu.gate", "weight", true, 256, 256, 256, 256},
         {FG_P "output_layer", "weight", false, 64, 256, 64, 256},
     };
+    // layers that contract a member-owned slice in the cluster kernel
+    l[1].kw = 48;                                   // conditioning_network.2
+    l[4].kw = 32;                                   // framewise conv GLU gate
+    l[11].kw = l[12].kw = l[13].kw = 32;            // GRU GLU gates
+    l[16].kw = 32;                                  // output layer
     return l;
 }
 
@@ -1313,6 +1454,7 @@ extern "C" int pm_fargan_destroy(pm_fargan_t h) {
     if (!h) return PM_OK;
     for (auto& l : h->layers) {
         if (l.packed) hipFree(l.packed);
+        if (l.packed_k) hipFree(l.packed_k);
         if (l.tmp_g) hipFree(l.tmp_g);
         if (l.tmp_v) hipFree(l.tmp_v);
     }
@@ -1320,21 +1462,35 @@ extern "C" int pm_fargan_destroy(pm_fargan_t h) {
     return PM_OK;
 }
 
-static int fargan_pack(pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) {
+template <class WT>
+static hipError_t fargan_pack_t(
+    FLayer& l, const float* w, size_t esize, hipStream_t s) {
     const int gru = l.rows == 768 ? 1 : 0;   // gate-interleaved GRU rows
     const size_t elems = (size_t)l.rpad * l.kpad;
-    if (!l.packed)
-        HIP_TRY(hipMalloc(&l.packed, elems * (h->dtype == PM_F32 ? 4 : 2)));
-    const unsigned grid = (unsigned)((elems + 255) / 256);
-    if (h->dtype == PM_F32)
-        hipLaunchKernelGGL(pm_fargan_pack_kernel<float>, dim3(grid), dim3(256),
-                           0, s, w, (float*)l.packed, l.rows, l.cols, l.rpad,
-                           l.kpad, gru);
-    else
-        hipLaunchKernelGGL(pm_fargan_pack_kernel<_Float16>, dim3(grid),
-                           dim3(256), 0, s, w, (_Float16*)l.packed, l.rows,
-                           l.cols, l.rpad, l.kpad, gru);
-    HIP_TRY(hipGetLastError());
+    hipError_t e;
+    if (!l.packed && (e = hipMalloc(&l.packed, elems * esize)) != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(pm_fargan_pack_kernel<WT>,
+                       dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s,
+                       w, (WT*)l.packed, l.rows, l.cols, l.rpad, l.kpad, gru, 0);
+    if (l.kw) {
+        // K-split copy: member g's sub-matrix W[:, g kw : (g + 1) kw]
+        const size_t sub = (size_t)l.rpad * l.kw;
+        if (!l.packed_k &&
+            (e = hipMalloc(&l.packed_k, FG_G * sub * esize)) != hipSuccess)
+            return e;
+        for (int g = 0; g < FG_G; ++g)
+            hipLaunchKernelGGL(pm_fargan_pack_kernel<WT>,
+                               dim3((unsigned)((sub + 255) / 256)), dim3(256),
+                               0, s, w, (WT*)l.packed_k + g * sub, l.rows,
+                               l.cols, l.rpad, l.kw, 0, g * l.kw);
+    }
+    return hipGetLastError();
+}
+
+static int fargan_pack(pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) {
+    if (h->dtype == PM_F32) HIP_TRY(fargan_pack_t<float>(l, w, 4, s));
+    else HIP_TRY(fargan_pack_t<_Float16>(l, w, 2, s));
     l.has = true;
     return PM_OK;
 }
@@ -1470,6 +1626,11 @@ static int fargan_launch(
     }
     w.skip = P(14); w.skip_glu = P(15); w.out = P(16);
     if (cluster_state) {
+        FarganSplitWeights<WT> ws;
+        auto K = [&](int i) { return (const WT*)h->layers[i].packed_k; };
+        ws.cond1 = K(1); ws.fwconv_glu = K(4);
+        for (int n = 0; n < 3; ++n) ws.gru_glu[n] = K(11 + n);
+        ws.out = K(16);
         // counters / payload / error word are re-initialised on every call
         HIP_TRY(hipMemsetAsync(cluster_state, 0, fargan_state_bytes(), s));
         FarganClusterArgs ca;
@@ -1491,7 +1652,7 @@ static int fargan_launch(
             hipError_t e = pm_ensure_dynamic_lds(
                 reinterpret_cast<const void*>(kern), (int)smem);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, block, smem, s, ca, w);
+            hipLaunchKernelGGL(kern, grid, block, smem, s, ca, w, ws);
             return hipGetLastError();
         };
         hipError_t e = U == 1 ? launch(pm_fargan_cluster_kernel<WT, 1>)

@@ -56,6 +56,13 @@ struct ElemF16 {
         *reinterpret_cast<half4*>(p) = __builtin_convertvector(w, half4);
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return (_Float16)v; }
+    // bias step (pm_pack_bias_step_kernel): c += b[co] for every column
+    __device__ static __forceinline__ void mma_bias(
+        const frag_t& a, floatx16& c) {
+        const _Float16 one = (_Float16)1.f;
+        const frag_t ones = {one, one, one, one, one, one, one, one};
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, c, 0, 0, 0);
+    }
 };
 
 struct ElemBF16 {
@@ -72,6 +79,12 @@ struct ElemBF16 {
         *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(w, bf16x4);
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return (__bf16)v; }
+    __device__ static __forceinline__ void mma_bias(
+        const frag_t& a, floatx16& c) {
+        const __bf16 one = (__bf16)1.f;
+        const frag_t ones = {one, one, one, one, one, one, one, one};
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, c, 0, 0, 0);
+    }
 };
 
 struct ElemF32 {
@@ -94,6 +107,11 @@ struct ElemF32 {
         *reinterpret_cast<float4*>(p) = v;
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return v; }
+    // k = 0 carries the bias (lanes 0-31), k = 1 (lanes 32-63) is zero
+    __device__ static __forceinline__ void mma_bias(
+        const frag_t& a, floatx16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.x, 1.f, c, 0, 0, 0);
+    }
 };
 
 // Bijective XCD-aware remap of a linear workgroup id: the dispatcher places

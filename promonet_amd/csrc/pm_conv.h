@@ -27,6 +27,11 @@
 //   frag[(((mt * NCH + c) * KT + jj) * KC + kc) * 64 + lane] = 8 elements:
 //     co = mt*32 + (lane & 31), ci = c*CH + kc*16 + (lane >> 5)*8 + e, tap jj
 // so one wave's A operand for one k16 step is 64 contiguous fragments.
+// MRF convolutions append one "bias step" (64 fragments) to every M tile's
+// stream (pm_pack_bias_step_kernel): the bias is added by one MFMA against an
+// all-ones B fragment, so an accumulator starts as `0 -> mfma(bias)` (no
+// register fill, no add in the epilogue) and a residual accumulates in place
+// (the fp32 trunk is the MFMA's C operand).
 // ---------------------------------------------------------------------------
 
 template <class ET, int CH, int NT, int XR_MAX>
@@ -185,30 +190,38 @@ __device__ __forceinline__ void mma_taps(
 #define PM_STAMP(args, i) ((void)0)
 #endif
 
-// The conv bias rides in the accumulator: the first MFMA of a tile takes the
-// bias vector as its C operand (no zero fill, no add in the epilogue). In the
-// 32x32 C/D layout register 4 g + r of a lane is channel 8 g + 4 (lane>>5) + r.
-template <int MTW>
-__device__ __forceinline__ void load_bias_vec(
-    floatx16 (&bv)[MTW], const float* __restrict__ bias, const int co_first) {
+// Bias step of a packed weight stream (see the layout comment above)
+template <class ET, int MTW>
+__device__ __forceinline__ void load_bias_frags(
+    typename ET::frag_t (&bf)[MTW],
+    const typename ET::frag_t* __restrict__ wbias, const int w_mt_stride) {
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) bf[mt] = wbias[mt * w_mt_stride];
+}
+
+// acc = bias: the tile's first MFMA takes the constant 0 as its C operand
+template <class ET, int MTW, int NTW>
+__device__ __forceinline__ void bias_start(
+    floatx16 (&acc)[MTW][NTW], const typename ET::frag_t (&bf)[MTW]) {
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 v = *reinterpret_cast<const float4*>(
-                bias + co_first + mt * 32 + 8 * g4);
-            bv[mt][4 * g4 + 0] = v.x; bv[mt][4 * g4 + 1] = v.y;
-            bv[mt][4 * g4 + 2] = v.z; bv[mt][4 * g4 + 3] = v.w;
+        for (int nt = 0; nt < NTW; ++nt) {
+            floatx16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                          0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            ET::mma_bias(bf[mt], c);
+            acc[mt][nt] = c;
         }
 }
 
-template <int MTW, int NTW>
-__device__ __forceinline__ void init_acc(
-    floatx16 (&acc)[MTW][NTW], const floatx16 (&bv)[MTW]) {
+// acc += bias (acc already holds the residual trunk)
+template <class ET, int MTW, int NTW>
+__device__ __forceinline__ void bias_add(
+    floatx16 (&acc)[MTW][NTW], const typename ET::frag_t (&bf)[MTW]) {
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = bv[mt];
+        for (int nt = 0; nt < NTW; ++nt) ET::mma_bias(bf[mt], acc[mt][nt]);
 }
 
 __device__ __forceinline__ float4 acc_quad(const floatx16& v, const int g4) {
@@ -222,10 +235,8 @@ __device__ __forceinline__ float4 acc_quad(const floatx16& v, const int g4) {
 struct PairArgs {
     const float* x;      // (B, L, C) fp32 trunk (pre-activation)
     float* out;          // (B, L, C)
-    const void* w1;      // packed conv1 weights (dilated)
-    const void* w2;      // packed conv2 weights (dilation 1)
-    const float* b1;     // (C)
-    const float* b2;     // (C)
+    const void* w1;      // packed conv1 weights (dilated) + bias step
+    const void* w2;      // packed conv2 weights (dilation 1) + bias step
     int B, L;
     int dilation;
     int mode;            // 0: out = y; 1: out = y * scale; 2: out += y * scale
@@ -253,9 +264,18 @@ __host__ __device__ constexpr int pair_smem_bytes(int d) {
     return ALIAS ? (x > inter ? x : inter) : x + inter;
 }
 
+// 4-wave workgroups may be asked to leave room for a second one on the CU
+// (2 waves per SIMD -> at most 256 registers)
+#ifndef PM_PAIR_MINWAVES4
+#define PM_PAIR_MINWAVES4 1
+#endif
+#ifndef PM_BLOCK_MINWAVES4
+#define PM_BLOCK_MINWAVES4 1
+#endif
 template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS>
-__global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
-    PairArgs a) {
+__global__ __launch_bounds__(WM * WN * 64,
+                             WM * WN == 4 && ET::ESZ == 2 ? PM_PAIR_MINWAVES4 : 1)
+void conv_pair_kernel(PairArgs a) {
     typedef typename ET::frag_t frag_t;
     constexpr int NCH = C / CH;
     constexpr int KC = CH / 16;
@@ -299,17 +319,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     const int t_first = t0 - H2 - hd;
 
     floatx16 acc[MTW][NTW];
-    floatx16 bv[MTW];
-    load_bias_vec<MTW>(bv, a.b1, wm * MTW * 32 + 4 * lh);
-    init_acc<MTW, NTW>(acc, bv);
 
     // ---------------- conv1: K-loop over staged channel chunks -------------
-    const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1) +
-                       (size_t)(wm * MTW) * (NCH * K * KC * 64) + lane;
-    const frag_t* w2 = reinterpret_cast<const frag_t*>(a.w2) +
-                       (size_t)(wm * MTW) * (NCH * K * KC * 64) + lane;
-    constexpr int W_MT_STRIDE = NCH * K * KC * 64;
+    constexpr int W_BIAS = NCH * K * KC * 64;       // bias step of a stream
+    constexpr int W_MT_STRIDE = W_BIAS + 64;
     constexpr int W_CHUNK = K * KC * 64;
+    const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1) +
+                       (size_t)(wm * MTW) * W_MT_STRIDE + lane;
+    const frag_t* w2 = reinterpret_cast<const frag_t*>(a.w2) +
+                       (size_t)(wm * MTW) * W_MT_STRIDE + lane;
+    frag_t bf[MTW];
+    load_bias_frags<ET, MTW>(bf, w1 + W_BIAS, W_MT_STRIDE);
     PM_STAMP(a, 0);
     const int lane_off_x =
         ((wn * NTW * 32) + ln) * SX + lh * 8 * ET::ESZ;
@@ -322,6 +342,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     stager.template store<true>(xbuf, XR, tid);
     __syncthreads();
     PM_STAMP(a, 1);
+    bias_start<ET, MTW, NTW>(acc, bf);
 
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
@@ -348,7 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     // ---------------- epilogue 1: lrelu, zero-pad mask -> LDS --------------
     // (bias already in the accumulator; the mask only on tiles that straddle
     // an utterance edge - a wave-uniform branch)
-    load_bias_vec<MTW>(bv, a.b2, wm * MTW * 32 + 4 * lh);
+    load_bias_frags<ET, MTW>(bf, w2 + W_BIAS, W_MT_STRIDE);
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         const int co_base = (wm * MTW + mt) * 32 + 4 * lh;
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
             }
         }
     }
-    init_acc<MTW, NTW>(acc, bv);
+    bias_start<ET, MTW, NTW>(acc, bf);
     __syncthreads();
     PM_STAMP(a, 3);
 
@@ -451,8 +472,9 @@ struct SingleArgs {
     int gbias_batch;      // 1 -> broadcast row 0
     int B, L, Cin, M;
     int Lout;             // output rows per utterance (== L except STFT)
-    int bins;             // EPI 1/2: DFT bins (output (B, bins, Lout))
+    int bins;             // EPI 1/2/3: DFT bins (output (B, bins, Lout))
     unsigned* maxbits;    // EPI 2: per-utterance max (order-preserving bits)
+    const float* grad;    // EPI 3: d loss / d magnitude, (B, bins, Lout)
     int lrelu;            // apply LeakyReLU to the input while staging
     int pad;              // rows of left padding of the staged tile
     // tap window start for an M row block (ConvTranspose phases): window
@@ -471,6 +493,9 @@ struct SingleArgs {
 //        out (B, bins, Lout) = sqrt(re^2 + im^2 + 1e-6)   spectrogram.py:53
 // EPI 2: out (B, bins, Lout) = 10 log10(max(1e-10, re^2 + im^2)) and the
 //        per-utterance maximum (librosa.amplitude_to_db, loudness.py:46)
+// EPI 3: backward of EPI 1, first half: out (B, Lout, M) channels-last =
+//        grad[bin] / magnitude * (re, im) - the cotangent of the framed DFT,
+//        which a second conv against the transposed basis overlap-adds
 __device__ __forceinline__ unsigned pm_float_order_bits(float f) {
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -586,6 +611,39 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
             }
         }
     }
+    } else if constexpr (EPI == 3) {
+    float* ob = a.out + (size_t)b * a.Lout * M;
+    const float* gb = a.grad + (size_t)b * a.bins * a.Lout;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int row_base = m0 + mt * 32 + 4 * lh;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = (wn * NTW + nt) * 32 + ln;
+            const int t = t0 + n;
+            if (t < a.Lout) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v[4];
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int bin = (row_base + 8 * g4) / 2 + pr;
+                        const float re = acc[mt][nt][4 * g4 + 2 * pr];
+                        const float im = acc[mt][nt][4 * g4 + 2 * pr + 1];
+                        float scale = 0.f;
+                        if (bin < a.bins)
+                            scale = gb[(size_t)bin * a.Lout + t] /
+                                    sqrtf(re * re + im * im + 1e-6f);
+                        v[2 * pr] = scale * re;
+                        v[2 * pr + 1] = scale * im;
+                    }
+                    *reinterpret_cast<float4*>(
+                        ob + (size_t)t * M + row_base + 8 * g4) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
     } else {
     float* ob = a.out + (size_t)b * a.bins * a.Lout;
     float local_max = -INFINITY;
@@ -641,10 +699,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
 struct Block3Args {
     const float* x;
     float* out;
-    const void* w1[3];
+    const void* w1[3];   // packed weights + bias step per iteration
     const void* w2[3];
-    const float* b1[3];
-    const float* b2[3];
     int dil[3];
     int niter;
     int B, L;
@@ -684,7 +740,8 @@ __device__ __forceinline__ void block3_body(
     constexpr int ROWS_T = NC + 2 * H2;
     constexpr int G = (ET::ESZ == 4) ? 2 : KC;
     constexpr int W_CHUNK = K * KC * 64;
-    constexpr int W_MT_STRIDE = NCH * W_CHUNK;
+    constexpr int W_BIAS = NCH * W_CHUNK;          // bias step of a stream
+    constexpr int W_MT_STRIDE = W_BIAS + 64;
 
     char* abuf = smem;
     char* tbuf = smem + ROWS_A * S;
@@ -761,13 +818,15 @@ __device__ __forceinline__ void block3_body(
 
     const int col_off = (wn * NTW * 32 + ln) * S + lh * 8 * ET::ESZ;
     floatx16 acc[MTW][NTW];
-    floatx16 bv[MTW];
-    load_bias_vec<MTW>(bv, a.b1[0], m_first + 4 * lh);
-    init_acc<MTW, NTW>(acc, bv);
+    frag_t bf[MTW];
     frag_t afirst[G][MTW];
-    load_a_group<ET, MTW, G>(
-        afirst, reinterpret_cast<const frag_t*>(a.w1[0]) +
-                    (size_t)(wm * MTW) * W_MT_STRIDE + lane, W_MT_STRIDE);
+    {
+        const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1[0]) +
+                           (size_t)(wm * MTW) * W_MT_STRIDE + lane;
+        load_bias_frags<ET, MTW>(bf, w1 + W_BIAS, W_MT_STRIDE);
+        load_a_group<ET, MTW, G>(afirst, w1, W_MT_STRIDE);
+    }
+    bias_start<ET, MTW, NTW>(acc, bf);
 
 #pragma unroll 1
     for (int it = 0; it < a.niter; ++it) {
@@ -785,7 +844,7 @@ __device__ __forceinline__ void block3_body(
                 d * S, w1 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
                 c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
         PM_STAMP(a, 2 + 4 * it);
-        load_bias_vec<MTW>(bv, a.b2[it], m_first + 4 * lh);
+        load_bias_frags<ET, MTW>(bf, w2 + W_BIAS, W_MT_STRIDE);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -814,16 +873,17 @@ __device__ __forceinline__ void block3_body(
                     }
                 }
             }
-        init_acc<MTW, NTW>(acc, bv);
+        // ---- conv2 (dilation 1) out of `t`, accumulated IN PLACE onto the
+        // fp32 trunk (the residual add is the MFMA's C operand) ----
+        bias_add<ET, MTW, NTW>(trunk, bf);
         __syncthreads();
         PM_STAMP(a, 3 + 4 * it);
 
-        // ---- conv2 (dilation 1) out of `t`, residual into the trunk ----
         const bool last = it + 1 == a.niter;
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c)
             mma_taps<ET, K, KC, MTW, NTW, G, S>(
-                acc, tbuf + col_off + c * CH * ET::ESZ, S,
+                trunk, tbuf + col_off + c * CH * ET::ESZ, S,
                 w2 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
                 c + 1 < NCH
                     ? w2 + (size_t)(c + 1) * W_CHUNK
@@ -831,12 +891,15 @@ __device__ __forceinline__ void block3_body(
                             : reinterpret_cast<const frag_t*>(a.w1[it + 1]) +
                                   (size_t)(wm * MTW) * W_MT_STRIDE + lane));
         PM_STAMP(a, 4 + 4 * it);
-        if (!last) load_bias_vec<MTW>(bv, a.b1[it + 1], m_first + 4 * lh);
+        if (!last)
+            load_bias_frags<ET, MTW>(
+                bf, reinterpret_cast<const frag_t*>(a.w1[it + 1]) +
+                        (size_t)(wm * MTW) * W_MT_STRIDE + lane + W_BIAS,
+                W_MT_STRIDE);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                trunk[mt][nt] += acc[mt][nt];
                 if (!last) {
                     const int col_first = (wn * NTW + nt) * 32;
                     const int col = col_first + ln;
@@ -865,7 +928,7 @@ __device__ __forceinline__ void block3_body(
                     }
                 }
             }
-        if (!last) init_acc<MTW, NTW>(acc, bv);
+        if (!last) bias_start<ET, MTW, NTW>(acc, bf);
         if (!last) __syncthreads();
         PM_STAMP(a, 5 + 4 * it);
     }
@@ -930,8 +993,9 @@ __device__ __forceinline__ void block3_body(
 }
 
 template <class ET, int C, int K, int WM, int WN, int NTW>
-__global__ __launch_bounds__(WM * WN * 64) void conv_block3_kernel(
-    Block3Args a) {
+__global__ __launch_bounds__(WM * WN * 64,
+                             WM * WN == 4 && ET::ESZ == 2 ? PM_BLOCK_MINWAVES4 : 1)
+void conv_block3_kernel(Block3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     floatx16 unused[(C / 32) / WM][NTW];
     block3_body<ET, C, K, WM, WN, NTW>(a, smem, unused);

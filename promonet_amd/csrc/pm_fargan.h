@@ -109,7 +109,7 @@ __host__ __device__ __forceinline__ int fg_gru_row(int gate, int j) {
 template <class WT>
 __global__ __launch_bounds__(256) void pm_fargan_pack_kernel(
     const float* __restrict__ w, WT* __restrict__ out, int rows, int cols,
-    int rpad, int kpad, int gru) {
+    int rpad, int kpad, int gru, int col0) {
     constexpr int VEC = FgVec<WT>::VEC;
     const long long total = (long long)rpad * kpad;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void pm_fargan_pack_kernel(
     const int e = i % VEC;
     const int row = (i / VEC) % rpad;
     const int blk = i / ((long long)VEC * rpad);
-    const int col = blk * VEC + e;
+    const int col = col0 + blk * VEC + e;      // col0: K-split sub-matrix
     int src = row;
     if (gru) src = ((row % 96) / 32) * 256 + (row / 96) * 32 + (row % 32);
     out[i] = (WT)((src < rows && col < cols) ? w[(size_t)src * cols + col]
@@ -308,36 +308,55 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
 // Cluster variant: FG_G = 8 workgroups cooperate on one utterance.
 //
 // One CU streams the 9.2 MB of weights at ~45 GB/s: 213 us per sub-frame step.
-// Here workgroup g of a cluster owns rows [g R / 8, (g + 1) R / 8) of every
-// layer, so each streams 1/8 of the weights; the dispatcher places block b on
-// XCD b % 8 and g = b % 8, so each XCD's 4 MB L2 keeps exactly its 1.15 MB
-// slice resident for ALL clusters. After every layer the 8 slices of the
-// output vector are exchanged through a per-cluster global buffer of 8-byte
-// {value, epoch} granules (the guide's tagged-granule hand-off):
+// Here every layer is split over the 8 members of a cluster, so each streams
+// 1/8 of the weights; the dispatcher places block b on XCD b % 8 and
+// g = b % 8, so each XCD's 4 MB L2 keeps exactly its 1.15 MB slice resident
+// for ALL clusters. What bounds a step is the number of inter-member
+// exchanges on its dependency chain (an L2-and-beyond round trip each), so
+// consecutive layers ALTERNATE the axis they are split on:
+//   row split  (R):  member g computes rows [g R / 8, (g + 1) R / 8) of
+//                    y = W x from the full (replicated) x -> owns a slice of y
+//   K split    (K):  the next layer contracts exactly that slice: member g
+//                    computes W[:, slice g] y_g for ALL rows -> partial sums
+// and only the partial sums cross members: every member adds the 8 partials
+// of every row in the same order (bit-identical replicas) and applies the
+// nonlinearity. A (R, K) pair of layers costs ONE exchange instead of two:
+//   framewise conv (R) + its GLU gate (K)            1 exchange
+//   3 x [GRU cell (R) + GLU gate (K)]                 3
+//   skip dense (R)                                    1  (vector exchange)
+//   skip GLU (R) + output layer (K)                   1
+// 6 per sub-frame step (was 11), and 2 instead of 3 for the per-frame
+// conditioning network (R, K, R).
+//
+// Exchange = per-cluster global buffer of 8-byte {value, epoch} granules (the
+// guide's tagged-granule hand-off):
 //   publish: one relaxed agent-scope 64-bit atomic store per element
 //            (write-through, `sc1`) - value and tag land together;
-//   consume: every thread polls ITS granule (relaxed `sc1` 64-bit load,
-//            s_sleep between tries) until the tag equals the epoch.
-// One L2 round trip per layer; no arrival counter, no vmcnt drain, no barrier
-// before the poll. Placement-independent (correct for any block -> XCD map),
-// two payload buffers alternate by epoch parity (a member can only write
-// epoch e after it has read every member's epoch e - 1, i.e. after every
-// member finished reading epoch e - 2 out of the same buffer), state is zeroed
-// by a memset node before every launch (tag 0 never matches: epochs start at
-// 1), every spin is bounded and trips a global error word.
+//   consume: a thread polls ITS granules (relaxed `sc1` 64-bit loads,
+//            s_sleep between tries) until every tag equals the epoch.
+// No arrival counter, no vmcnt drain, no barrier before the poll.
+// Placement-independent (correct for any block -> XCD map), two payload
+// buffers alternate by epoch parity (a member can only write epoch e after it
+// has read every member's epoch e - 1, i.e. after every member finished
+// reading epoch e - 2 out of the same buffer), state is zeroed by a memset
+// node before every launch (tag 0 never matches: epochs start at 1), every
+// spin is bounded and trips a global error word.
 // All other state (GRU states, sample history) is replicated per workgroup.
 // ===========================================================================
 #define FG_G 8
 
 #define FG_UMAX 4              // utterances a cluster advances in lockstep
+#define FG_SLOTS 416           // granules one member publishes per exchange (max 384 + 32)
 
 struct FgCluster {
-    unsigned long long* buf;   // [2][FG_UMAX][768] {value bits, epoch} granules
+    unsigned long long* buf;   // [2][FG_UMAX][FG_G][FG_SLOTS] granules
     unsigned* error;           // global: set when a bounded spin gave up
     unsigned epoch;            // epochs count from 1
+    int g;                     // this member
 };
 
 #define FG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define FG_CSTATE (2 * FG_UMAX * FG_G * FG_SLOTS * 2 + 16)   // uint32 words per cluster
 
 // Per-utterance recurrent state + scratch of one cluster member, in LDS.
 struct FgLds {
@@ -350,7 +369,7 @@ struct FgLds {
     float hid[3][FG_HOP];
     float f1[FG_HOP];
     float prev[FG_PREV];
-    float fresh[FG_SUB];
+    float own[64];             // this member's slice of a row-split output
     float part[FG_THREADS];
     float part2[FG_THREADS];
 };
@@ -358,56 +377,165 @@ static_assert(sizeof(FgLds) % 16 == 0, "16-byte aligned per-utterance state");
 #define FG_OFF(field) (offsetof(FgLds, field) / sizeof(float))
 #define FG_LSTRIDE (sizeof(FgLds) / sizeof(float))
 
-// `mine[u]` (valid for tid < nmine) = element r0 + tid of utterance u's
-// `total`-long vector; on return field `dst` of every utterance's FgLds holds
-// the whole vector in every member's LDS. Callers guarantee (barrier at the
-// end of fg_slice) that nobody still reads dst's previous content.
-template <int U>
+__device__ __forceinline__ unsigned long long* fg_granule(
+    const FgCluster& c, unsigned epoch, int u, int member, int slot) {
+    return c.buf + (((size_t)(epoch & 1u) * FG_UMAX + u) * FG_G + member) *
+                       FG_SLOTS + slot;
+}
+
+// Poll N granules per utterance until every tag equals the epoch (bounded).
+template <int U, int N>
+__device__ __forceinline__ void fg_poll(
+    FgCluster& c, unsigned epoch, unsigned long long* const (&src)[U][N],
+    float (&val)[U][N]) {
+    unsigned long long v[U][N];
+    unsigned spins = 0;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                v[u][i] = __hip_atomic_load(src[u][i], FG_RLX);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                all &= (unsigned)(v[u][i] >> 32) == epoch;
+        if (all) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0u &&
+            (spins > (1u << 22) || __hip_atomic_load(c.error, FG_RLX))) {
+            __hip_atomic_store(c.error, 1u, FG_RLX);
+            break;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            val[u][i] = __uint_as_float((unsigned)v[u][i]);
+}
+
+// Vector exchange: `mine[u]` (valid for tid < N) = element g N + tid of
+// utterance u's 8 N-long vector; on return field `dst` of every utterance's
+// FgLds holds the whole vector in every member's LDS. Callers guarantee (a
+// barrier since the last read) that nobody still reads dst's old content.
+template <int U, int N>
 __device__ __forceinline__ void fg_exchange(
-    FgCluster& c, const float (&mine)[U], int r0, int nmine, float* lds,
-    int dst, int total, int tid) {
+    FgCluster& c, const float (&mine)[U], float* lds, int dst, int tid) {
     c.epoch += 1u;
     const unsigned epoch = c.epoch;
-    unsigned long long* buf = c.buf + (epoch & 1u) * (FG_UMAX * 768u);
-    if (tid < nmine) {
+    if (tid < N) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
             __hip_atomic_store(
-                buf + u * 768 + r0 + tid,
+                fg_granule(c, epoch, u, c.g, tid),
                 ((unsigned long long)epoch << 32) | __float_as_uint(mine[u]),
                 FG_RLX);
     }
-    if (tid < total) {
-        // the U granules of this thread are polled together: their loads are
-        // independent, so a try costs one round trip, not U
-        unsigned long long v[U];
-        unsigned spins = 0;
-        for (;;) {
-            bool all = true;
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                v[u] = __hip_atomic_load(buf + u * 768 + tid, FG_RLX);
-#pragma unroll
-            for (int u = 0; u < U; ++u) all &= (unsigned)(v[u] >> 32) == epoch;
-            if (all) break;
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0u &&
-                (spins > (1u << 22) || __hip_atomic_load(c.error, FG_RLX))) {
-                __hip_atomic_store(c.error, 1u, FG_RLX);
-                break;
-            }
-        }
+    if (tid < FG_G * N) {
+        unsigned long long* src[U][1];
+        float val[U][1];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            lds[u * FG_LSTRIDE + dst + tid] = __uint_as_float((unsigned)v[u]);
+            src[u][0] = fg_granule(c, epoch, u, tid / N, tid % N);
+        fg_poll<U, 1>(c, epoch, src, val);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            lds[u * FG_LSTRIDE + dst + tid] = val[u][0];
     }
     __syncthreads();
 }
 
-// This member's RW rows (r0 .. r0 + RW) of y_u = W x_u for the U utterances:
-// every thread takes one (row, K-slice) pair, loads each 16-byte weight block
-// ONCE and dots it with the U input vectors (LDS fields xa / xb of every
-// FgLds); partial sums meet in LDS. sum[u] is valid in threads tid < RW.
+// Partial-sum exchange after a K-split layer. `part[u]` (valid for tid < R) =
+// this member's partial sum of row tid; `extra[u]` (valid for tid < E) = this
+// member's element g E + tid of an 8 E = R long vector that travels with the
+// sums (the gated activation itself). On return, for tid < R: total[u] = the
+// sum over members 0..7, in that order, of row tid's partials (identical in
+// every member), ext[u] = element tid of the gathered vector.
+// Q = FG_THREADS / R threads share the 8 polls of a row; their partial
+// totals meet in LDS (field `part`, which the caller's fg_slice is done with).
+template <int U, int R, int E>
+__device__ __forceinline__ void fg_exchange_sum(
+    FgCluster& c, const float (&part)[U], const float (&extra)[U], float* lds,
+    int tid, float (&total)[U], float (&ext)[U]) {
+    constexpr int Q = FG_THREADS / R;          // 3 (R 256), 2 (384), 12 (64)
+    constexpr int QN = Q > FG_G ? FG_G : Q;    // polling threads per row
+    constexpr int NG = (FG_G + QN - 1) / QN;   // granules per polling thread
+    static_assert(QN * NG >= FG_G && R + E <= FG_SLOTS, "exchange geometry");
+    c.epoch += 1u;
+    const unsigned epoch = c.epoch;
+    if (tid < R) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            __hip_atomic_store(
+                fg_granule(c, epoch, u, c.g, tid),
+                ((unsigned long long)epoch << 32) | __float_as_uint(part[u]),
+                FG_RLX);
+    }
+    if (E > 0 && tid < E) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            __hip_atomic_store(
+                fg_granule(c, epoch, u, c.g, R + tid),
+                ((unsigned long long)epoch << 32) | __float_as_uint(extra[u]),
+                FG_RLX);
+    }
+    const int row = tid % R, q = tid / R;
+    if (q < QN) {
+        // members q NG .. q NG + NG - 1 (clamped: a duplicate poll of member
+        // 7 is masked out of the sum below)
+        unsigned long long* src[U][NG];
+        float val[U][NG];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int m = q * NG + i;
+                src[u][i] = fg_granule(c, epoch, u, m < FG_G ? m : FG_G - 1, row);
+            }
+        fg_poll<U, NG>(c, epoch, src, val);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+                if (q * NG + i < FG_G) sum += val[u][i];
+            lds[u * FG_LSTRIDE + FG_OFF(part) + tid] = sum;
+        }
+    }
+    if (E > 0 && tid < R) {
+        unsigned long long* src[U][1];
+        float val[U][1];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            src[u][0] = fg_granule(c, epoch, u, tid / (E > 0 ? E : 1),
+                                   R + tid % (E > 0 ? E : 1));
+        fg_poll<U, 1>(c, epoch, src, val);
+#pragma unroll
+        for (int u = 0; u < U; ++u) ext[u] = val[u][0];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float t = 0.f;
+        if (tid < R) {
+#pragma unroll
+            for (int k = 0; k < QN; ++k)
+                t += lds[u * FG_LSTRIDE + FG_OFF(part) + tid + k * R];
+        }
+        total[u] = t;
+    }
+    __syncthreads();
+}
+
+// RW rows (r0 .. r0 + RW of a matrix packed with RPAD rows) of y_u = W x_u
+// for the U utterances: every thread takes one (row, K-slice) pair, loads
+// each 16-byte weight block ONCE and dots it with the U input vectors (LDS
+// fields xa / xb of every FgLds); partial sums meet in LDS. sum[u] is valid
+// in threads tid < RW. Row split: RW = R / 8 rows of the full-K matrix;
+// K split: all RW = RPAD = R rows of this member's (R x K / 8) sub-matrix.
 template <class WT, int RW, int RPAD, int U>
 __device__ __forceinline__ void fg_slice(
     const WT* __restrict__ w, const float* lds, int xa, int xb, int split,
@@ -453,14 +581,23 @@ __device__ __forceinline__ void fg_slice(
     __syncthreads();
 }
 
+// K-split copies of the layers that contract a member-owned slice: member g's
+// (R x K / 8) sub-matrix W[:, g K / 8 : (g + 1) K / 8], packed like a matrix
+// of its own, the 8 of them back to back.
+template <class WT>
+struct FarganSplitWeights {
+    const WT* cond1;          // 8 x (384 x 48)
+    const WT* fwconv_glu;     // 8 x (256 x 32)
+    const WT* gru_glu[3];     // 8 x (256 x 32)
+    const WT* out;            // 8 x (64 x 32)
+};
+
 struct FarganClusterArgs {
     FarganArgs f;
-    unsigned* state;      // per cluster: [2][FG_UMAX][768] granules (+ pad)
+    unsigned* state;      // per cluster: FG_CSTATE words of granules
     unsigned* error;
     int nclusters;
 };
-
-#define FG_CSTATE (2 * FG_UMAX * 768 * 2 + 16)   // uint32 words per cluster
 
 // U utterances per cluster advance in lockstep: the weight slice is read once
 // per layer for all of them and one exchange carries U vectors, so the
@@ -468,7 +605,7 @@ struct FarganClusterArgs {
 // the batch <= 32 case (one utterance per cluster, 32 clusters = 256 CUs).
 template <class WT, int U>
 __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
-    FarganClusterArgs ca, FarganWeights<WT> w) {
+    FarganClusterArgs ca, FarganWeights<WT> w, FarganSplitWeights<WT> ws) {
     const FarganArgs& a = ca.f;
     constexpr int NT = FG_THREADS;
     constexpr int CPAD = 376;
@@ -485,6 +622,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
         ca.state + (size_t)cluster * FG_CSTATE);
     c.error = ca.error;
     c.epoch = 0;
+    c.g = g;
 
 #pragma unroll 1
     for (int u0 = cluster * U; u0 < a.B; u0 += ca.nclusters * U) {
@@ -503,6 +641,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
             for (int i = tid; i < 3 * FG_HOP; i += NT) (&L[u].hid[0][0])[i] = 0.f;
             for (int i = tid; i < 2 * FG_SUBIN + 8; i += NT) L[u].subin[i] = 0.f;
             for (int i = tid; i < CPAD; i += NT) L[u].condin[i] = 0.f;
+            for (int i = tid; i < 384; i += NT) { L[u].c1[i] = 0.f; L[u].c2[i] = 0.f; }
             for (int i = tid; i < FG_PREV; i += NT)
                 L[u].prev[i] = a.previous
                     ? a.previous[(size_t)(a.previous_batch == 1 ? 0 : ut[u]) *
@@ -526,23 +665,29 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 period[u] = (int)rintf(row[a.nfeat]);
             }
             __syncthreads();
-            float v[U], m[U];
-            // conditioning network: 384 / 384 / 512 rows -> 48 / 48 / 64 each
+            float v[U], m[U], tot[U], ext[U];
+            // ---- conditioning network (fargan.py:139-160): R, K, R ----
             fg_slice<WT, 48, 384, U>(w.cond[0], lds, FG_OFF(condin), FG_OFF(condin),
                                      CPAD, CPAD, g * 48, lds, tid, v);
+            if (tid < 48) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
-            fg_exchange<U>(c, m, g * 48, 48, lds, FG_OFF(c1), 384, tid);
-            fg_slice<WT, 48, 384, U>(w.cond[1], lds, FG_OFF(c1), FG_OFF(c1), CPAD,
-                                     CPAD, g * 48, lds, tid, v);
+                for (int u = 0; u < U; ++u) L[u].c1[g * 48 + tid] = tanhf(v[u]);
+            }
+            __syncthreads();
+            fg_slice<WT, 384, 384, U>(ws.cond1 + (size_t)g * (384 * 48), lds,
+                                      FG_OFF(c1) + g * 48, FG_OFF(c1) + g * 48,
+                                      48, 48, 0, lds, tid, v);
+            fg_exchange_sum<U, 384, 0>(c, v, v, lds, tid, tot, ext);
+            if (tid < 384) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
-            fg_exchange<U>(c, m, g * 48, 48, lds, FG_OFF(c2), 384, tid);
+                for (int u = 0; u < U; ++u) L[u].c2[tid] = tanhf(tot[u]);
+            }
+            __syncthreads();
             fg_slice<WT, 64, 512, U>(w.cond[2], lds, FG_OFF(c2), FG_OFF(c2), CPAD,
                                      CPAD, g * 64, lds, tid, v);
 #pragma unroll
             for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
-            fg_exchange<U>(c, m, g * 64, 64, lds, FG_OFF(cond), 512, tid);
+            fg_exchange<U, 64>(c, m, lds, FG_OFF(cond), tid);
 
 #pragma unroll 1
             for (int s = 0; s < 4; ++s) {
@@ -569,19 +714,27 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 __syncthreads();
 
-                // framewise conv + GLU
+                // ---- framewise conv (R) + its GLU gate (K): 1 exchange ----
                 fg_slice<WT, 32, 256, U>(w.fwconv, lds, FG_OFF(subin), FG_OFF(subin),
                                          520, 520, g * 32, lds, tid, v);
 #pragma unroll
-                for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
-                fg_exchange<U>(c, m, g * 32, 32, lds, FG_OFF(f1), 256, tid);
-                fg_slice<WT, 32, 256, U>(w.fwconv_glu, lds, FG_OFF(f1), FG_OFF(f1),
-                                         256, 256, g * 32, lds, tid, v);
+                for (int u = 0; u < U; ++u) {
+                    m[u] = tanhf(v[u]);
+                    if (tid < 32) L[u].own[tid] = m[u];
+                }
+                __syncthreads();
+                fg_slice<WT, 256, 256, U>(ws.fwconv_glu + (size_t)g * (256 * 32),
+                                          lds, FG_OFF(own), FG_OFF(own), 32, 32, 0,
+                                          lds, tid, v);
+                fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                if (tid < 256) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    m[u] = tid < 32 ? L[u].f1[g * 32 + tid] * fg_sigmoid(v[u]) : 0.f;
-                fg_exchange<U>(c, m, g * 32, 32, lds, FG_OFF(skipbuf) + 768, 256, tid);
+                    for (int u = 0; u < U; ++u)
+                        L[u].skipbuf[768 + tid] = ext[u] * fg_sigmoid(tot[u]);
+                }
+                __syncthreads();
 
+                // ---- three GRU cells (R) + GLU gates (K): 1 exchange each ----
 #pragma unroll 1
                 for (int n = 0; n < 3; ++n) {
                     const int xa = n == 0 ? FG_OFF(skipbuf) + 768
@@ -611,50 +764,54 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                             const float z = fg_sigmoid(p2[32 + tid] + p2[128 + tid]);
                             const float nn = tanhf(p2[64 + tid] + r * p2[160 + tid]);
                             hnew = (1.f - z) * nn + z * L[u].hid[n][g * 32 + tid];
+                            L[u].own[tid] = hnew;
                         }
                         m[u] = hnew;
                     }
                     __syncthreads();
-                    fg_exchange<U>(c, m, g * 32, 32, lds, hoff, 256, tid);
-                    fg_slice<WT, 32, 256, U>(w.gru_glu[n], lds, hoff, hoff, 256, 256,
-                                             g * 32, lds, tid, v);
+                    fg_slice<WT, 256, 256, U>(
+                        ws.gru_glu[n] + (size_t)g * (256 * 32), lds, FG_OFF(own),
+                        FG_OFF(own), 32, 32, 0, lds, tid, v);
+                    fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                    if (tid < 256) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        m[u] = tid < 32
-                            ? L[u].hid[n][g * 32 + tid] * fg_sigmoid(v[u]) : 0.f;
-                    fg_exchange<U>(c, m, g * 32, 32, lds,
-                                   FG_OFF(skipbuf) + n * 256, 256, tid);
+                        for (int u = 0; u < U; ++u) {
+                            L[u].hid[n][tid] = ext[u];
+                            L[u].skipbuf[n * 256 + tid] =
+                                ext[u] * fg_sigmoid(tot[u]);
+                        }
+                    }
+                    __syncthreads();
                 }
 
+                // ---- skip dense (R): vector exchange ----
                 fg_slice<WT, 32, 256, U>(w.skip, lds, FG_OFF(skipbuf), FG_OFF(skipbuf),
                                          FG_SKIP, FG_SKIP, g * 32, lds, tid, v);
 #pragma unroll
                 for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
-                fg_exchange<U>(c, m, g * 32, 32, lds, FG_OFF(f1), 256, tid);
+                fg_exchange<U, 32>(c, m, lds, FG_OFF(f1), tid);
+                // ---- skip GLU (R) + output layer (K): 1 exchange ----
                 fg_slice<WT, 32, 256, U>(w.skip_glu, lds, FG_OFF(f1), FG_OFF(f1), 256,
                                          256, g * 32, lds, tid, v);
-                // f1 is both the GLU input and the exchange target: the gated
-                // values are complete (barrier) before anyone overwrites it
+                if (tid < 32) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    m[u] = tid < 32 ? L[u].f1[g * 32 + tid] * fg_sigmoid(v[u]) : 0.f;
-                __syncthreads();
-                fg_exchange<U>(c, m, g * 32, 32, lds, FG_OFF(f1), 256, tid);
-                fg_slice<WT, 8, 64, U>(w.out, lds, FG_OFF(f1), FG_OFF(f1), 256, 256,
-                                       g * 8, lds, tid, v);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    m[u] = tanhf(v[u]);
-                    if (tid < 8 && live[u])
-                        a.out[((size_t)ut[u] * T + t) * FG_HOP + s * FG_SUB +
-                              g * 8 + tid] = m[u];
+                    for (int u = 0; u < U; ++u)
+                        L[u].own[tid] = L[u].f1[g * 32 + tid] * fg_sigmoid(v[u]);
                 }
-                fg_exchange<U>(c, m, g * 8, 8, lds, FG_OFF(fresh), FG_SUB, tid);
+                __syncthreads();
+                fg_slice<WT, 64, 64, U>(ws.out + (size_t)g * (64 * 32), lds,
+                                        FG_OFF(own), FG_OFF(own), 32, 32, 0, lds,
+                                        tid, v);
+                fg_exchange_sum<U, 64, 0>(c, v, v, lds, tid, tot, ext);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     FgLds& S = L[u];
                     if (tid < FG_SUB) {
-                        S.prev[(base + tid) & (FG_PREV - 1)] = S.fresh[tid];
+                        const float sample = tanhf(tot[u]);
+                        if (tid / 8 == g && live[u])
+                            a.out[((size_t)ut[u] * T + t) * FG_HOP + s * FG_SUB +
+                                  tid] = sample;
+                        S.prev[(base + tid) & (FG_PREV - 1)] = sample;
                     } else if (tid >= 256 && tid < 256 + FG_SUBIN) {
                         S.subin[FG_SUBIN + tid - 256] = S.subin[tid - 256];
                     }

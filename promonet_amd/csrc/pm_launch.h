@@ -80,11 +80,19 @@ template <class ET, int C> struct PairCfg;
 // 192 columns per weight fetch (LDS tiles aliased to fit): the pair kernels
 // run at the power wall with the L2 94 % busy streaming weights, so fewer L2
 // bytes per MFMA is what buys clock (measured -7 % on k 7 / k 11).
+#ifdef PM_EXP_PAIR256   // experiment: 64 x 128 wave tiles, 256-column workgroup tiles
+template <> struct PairCfg<ElemF16, 256> { enum { WM = 4, WN = 2, NTW = 4, CH = 32, ALIAS = 1 }; };
+#else
 template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 6, CH = 64, ALIAS = 1 }; };
+#endif
 // C = 128 alternatives measured and dropped: 384-column tiles with CH = 32
 // (neutral), two 4-wave 128-column workgroups per CU (neutral: L2 weight
 // traffic doubles), one fat wave per SIMD with 64 x 128 tiles (+1...+4 %).
+#ifdef PM_EXP_PAIR128   // experiment: 4 waves of 64 x 128 tiles, two workgroups per CU
+template <> struct PairCfg<ElemF16, 128> { enum { WM = 2, WN = 2, NTW = 4, CH = 32, ALIAS = 1 }; };
+#else
 template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0 }; };
+#endif
 template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2, CH = 64, ALIAS = 0 }; };
 template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
 template <int C> struct PairCfg<ElemBF16, C> : PairCfg<ElemF16, C> {};
@@ -100,8 +108,9 @@ template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 
 // third / half of the per-tile critical path. More halo recompute and weight
 // traffic per column, so only below PM_NARROW_BELOW workgroups.
 template <class ET, int C> struct PairCfgNarrow : PairCfg<ET, C> {};
-template <> struct PairCfgNarrow<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 2, CH = 64, ALIAS = 1 }; };
-template <> struct PairCfgNarrow<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2, CH = 64, ALIAS = 0 }; };
+// (CH must equal the wide variant's: both read the same packed weights)
+template <> struct PairCfgNarrow<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 2, CH = PairCfg<ElemF16, 256>::CH, ALIAS = 1 }; };
+template <> struct PairCfgNarrow<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2, CH = PairCfg<ElemF16, 128>::CH, ALIAS = 0 }; };
 template <> struct PairCfgNarrow<ElemBF16, 256> : PairCfgNarrow<ElemF16, 256> {};
 template <> struct PairCfgNarrow<ElemBF16, 128> : PairCfgNarrow<ElemF16, 128> {};
 #define PM_NARROW_BELOW 150   // 3x the tiles must still fit ~2 rounds of 256 CUs
@@ -423,13 +432,20 @@ hipError_t pm_launch_single(
 }
 
 // Framed DFT (STFT) as a 4-tap conv over the hop-reshaped padded audio:
-// exact-fp32 MFMA only. epi 1: magnitude, 2: dB + utterance max.
+// exact-fp32 MFMA only. epi 1: magnitude, 2: dB + utterance max, 3: the DFT
+// cotangent grad / magnitude * (re, im) (backward, first half), 0: the
+// overlap-add conv of that cotangent against the transposed basis (backward,
+// second half: C_in = 1088 -> 256 samples of one hop, 4 taps).
 #ifdef PM_INSTANTIATE_STFT
 hipError_t pm_launch_stft(int epi, const SingleArgs& a, hipStream_t s) {
     if (epi == 1)
         return launch_single_cfg<ElemF32, 4, 4, 64, 2, 2, 1, 2, 1>(a, s);
     if (epi == 2)
         return launch_single_cfg<ElemF32, 4, 4, 64, 2, 2, 1, 2, 2>(a, s);
+    if (epi == 3)
+        return launch_single_cfg<ElemF32, 4, 4, 64, 2, 2, 1, 2, 3>(a, s);
+    if (epi == 0)
+        return launch_single_cfg<ElemF32, 4, 4, 64, 2, 2, 1, 2, 0>(a, s);
     return hipErrorInvalidValue;
 }
 #endif

@@ -45,7 +45,8 @@ struct PackArgs {
     int cout_pad, cin_pad;     // padded
     int mtiles, nch, ch, kt;   // packed geometry (kc = ch / 16)
     int r, p;                  // ConvTranspose stride / padding
-    long long total;           // packed elements
+    int bias_step;             // 1: each M tile's stream ends with a bias step
+    long long total;           // packed elements (weights, without bias steps)
 };
 
 template <class ET>
@@ -75,7 +76,36 @@ __global__ __launch_bounds__(256) void pm_pack_kernel(PackArgs a) {
         if (co < a.cout && ci < a.cin && jw >= 0 && jw < a.k)
             v = a.w[((size_t)ci * a.cout + co) * a.k + jw];
     }
-    reinterpret_cast<typename ET::lds_t*>(a.out)[idx] = ET::cvt(v);
+    // with bias steps the stream of M tile mt is 512 elements longer
+    const long long dst = idx + (a.bias_step ? (long long)mt * 512 : 0);
+    reinterpret_cast<typename ET::lds_t*>(a.out)[dst] = ET::cvt(v);
+}
+
+// The conv bias as one more k16 step of the weight stream ("bias step", the
+// last 64 fragments of every M tile's stream): A[co][k] = {hi(b), lo(b), 0...}
+// in the lanes holding k = 0..7 and zeros elsewhere; multiplied with an
+// all-ones B fragment the MFMA adds b[co] to every column of the tile, exact
+// to the operand type's DOUBLE precision (hi + lo split; fp32: b itself).
+// The accumulator then needs neither a bias fill nor an add in the epilogue.
+template <class ET>
+__global__ __launch_bounds__(256) void pm_pack_bias_step_kernel(
+    const float* __restrict__ bias, void* out, int cout, int mtiles,
+    long long weights_per_mt) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= mtiles * 512) return;
+    const int mt = idx / 512, r = idx % 512;
+    const int lane = r / 8, e = r % 8;
+    const int co = mt * 32 + (lane & 31);
+    typedef typename ET::lds_t T;
+    T v = ET::cvt(0.f);
+    if (lane < 32 && co < cout) {
+        const float b = bias[co];
+        const T hi = ET::cvt(b);
+        if (e == 0) v = hi;
+        if (e == 1 && ET::ESZ == 2) v = ET::cvt(b - (float)hi);
+    }
+    reinterpret_cast<T*>(out)[(long long)mt * (weights_per_mt + 512) +
+                              weights_per_mt + r] = v;
 }
 
 // dst[i] = i < n ? src[i] : 0  for i < n_pad; optionally tiled `rep` times
@@ -307,7 +337,7 @@ __global__ void pm_global_features_kernel(
     const int W = S + (sbr ? 1 : 0) + (lr ? 1 : 0);
     for (int i = threadIdx.x; i < S; i += blockDim.x)
         out[(size_t)b * W + i] =
-            valid ? table[(size_t)spk * S + i] : __builtin_nanf("");
+            valid ? table[(size_t)spk * S + i] : __uint_as_float(0x7fc00000u);
     if (threadIdx.x == 0) {
         int c = S;
         if (sbr) out[(size_t)b * W + c++] = sbr[b];

@@ -25,10 +25,22 @@ def from_audio(
     if log_dynamic_range_compression_threshold is None:
         log_dynamic_range_compression_threshold = \
             promonet_amd.LOG_DYNAMIC_RANGE_COMPRESSION_THRESHOLD
-    lib = _lib.lib()
     _lib.require_gpu(audio)
     flat = audio.squeeze(1) if audio.ndim == 3 else audio
     flat = flat.to(torch.float32).contiguous()
+    if torch.is_grad_enabled() and flat.requires_grad:
+        # training-side use (the mel loss, train/core.py:277-305): keep the
+        # graph through the HIP kernels
+        out = _Magnitude.apply(flat)
+    else:
+        out = _magnitude(flat)
+    if mels:
+        out = linear_to_mel(out, log_dynamic_range_compression_threshold)
+    return out.squeeze(0)
+
+
+def _magnitude(flat):
+    lib = _lib.lib()
     batch, samples = flat.shape
     frames = samples // promonet_amd.HOPSIZE
     bins = promonet_amd.NUM_FFT // 2 + 1
@@ -40,9 +52,34 @@ def from_audio(
         _lib.check(lib.pm_stft_magnitude(
             _lib.ptr(flat), _lib.ptr(out), batch, samples,
             scratch.data_ptr(), scratch.numel(), _lib.stream()))
-    if mels:
-        out = linear_to_mel(out, log_dynamic_range_compression_threshold)
-    return out.squeeze(0)
+    return out
+
+
+class _Magnitude(torch.autograd.Function):
+    """spectrogram magnitude with a HIP backward: the framed DFT is a linear
+    map, so its adjoint is the overlap-add of grad / |X| * (re, im) against
+    the transposed windowed basis (pm_stft_magnitude_backward)."""
+
+    @staticmethod
+    def forward(ctx, flat):
+        ctx.save_for_backward(flat)
+        return _magnitude(flat)
+
+    @staticmethod
+    def backward(ctx, grad):
+        flat, = ctx.saved_tensors
+        lib = _lib.lib()
+        grad = grad.to(torch.float32).contiguous()
+        batch, samples = flat.shape
+        result = torch.empty_like(flat)
+        with torch.cuda.device(flat.device):
+            size = lib.pm_stft_backward_scratch_bytes(batch, samples)
+            scratch = torch.empty(
+                max(size, 1), dtype=torch.uint8, device=flat.device)
+            _lib.check(lib.pm_stft_magnitude_backward(
+                _lib.ptr(flat), _lib.ptr(grad), _lib.ptr(result), batch,
+                samples, scratch.data_ptr(), scratch.numel(), _lib.stream()))
+        return result
 
 
 def from_file(
@@ -126,18 +163,56 @@ def linear_to_mel(spectrogram, log_dynamic_range_compression_threshold=None):
     """log(mel_basis @ spectrogram), optional clamp (spectrogram.py:111-133).
     The basis is cached per device (the reference rebuilds it on every call
     through a misnamed cache attribute, :117 vs :124)."""
-    lib = _lib.lib()
     _lib.require_gpu(spectrogram)
     squeeze = spectrogram.ndim == 2
     spec = (spectrogram[None] if squeeze else spectrogram).to(
         torch.float32).contiguous()
-    batch, bins, frames = spec.shape
     basis = mel_basis().to(spec.device).contiguous()
-    out = torch.empty(batch, basis.shape[0], frames, device=spec.device)
     threshold = log_dynamic_range_compression_threshold
+    if torch.is_grad_enabled() and spec.requires_grad:
+        out = _LinearToMel.apply(spec, basis, threshold)
+    else:
+        out = _linear_to_mel(spec, basis, threshold)
+    return out[0] if squeeze else out
+
+
+def _linear_to_mel(spec, basis, threshold):
+    lib = _lib.lib()
+    batch, bins, frames = spec.shape
+    out = torch.empty(batch, basis.shape[0], frames, device=spec.device)
     with torch.cuda.device(spec.device):
         _lib.check(lib.pm_linear_to_mel(
             _lib.ptr(spec), _lib.ptr(basis), _lib.ptr(out), batch, bins,
             basis.shape[0], frames, int(threshold is not None),
             float(threshold or 0.), _lib.stream()))
-    return out[0] if squeeze else out
+    return out
+
+
+class _LinearToMel(torch.autograd.Function):
+    """log(basis @ spec) (clamped) with a HIP backward
+    (pm_linear_to_mel_backward); the clamp passes gradient where the forward
+    value is >= the threshold, as torch.clamp does."""
+
+    @staticmethod
+    def forward(ctx, spec, basis, threshold):
+        ctx.save_for_backward(spec, basis)
+        ctx.threshold = threshold
+        return _linear_to_mel(spec, basis, threshold)
+
+    @staticmethod
+    def backward(ctx, grad):
+        spec, basis = ctx.saved_tensors
+        lib = _lib.lib()
+        grad = grad.to(torch.float32).contiguous()
+        batch, bins, frames = spec.shape
+        result = torch.empty_like(spec)
+        scratch = torch.empty(
+            batch, basis.shape[0], frames, device=spec.device)
+        threshold = ctx.threshold
+        with torch.cuda.device(spec.device):
+            _lib.check(lib.pm_linear_to_mel_backward(
+                _lib.ptr(spec), _lib.ptr(basis), _lib.ptr(grad),
+                _lib.ptr(result), _lib.ptr(scratch), batch, bins,
+                basis.shape[0], frames, int(threshold is not None),
+                float(threshold or 0.), _lib.stream()))
+        return result, None, None

@@ -302,8 +302,12 @@ def test_conditioning_variants_golden(device, which, dtype):
     assert max_abs(features, golden['features']) < 1e-6
     assert max_abs(global_features, golden['global_features']) < 2e-6
     error = max_abs(audio, golden['audio'])
-    print(f'{which} {dtype}: max-abs {error:.3e}')
-    assert error < GATE[dtype]
+    scale = golden['audio'].abs().max().item()
+    print(f'{which} {dtype}: max-abs {error:.3e} (abs-max {scale:.3f})')
+    # this 32-channel vocoder's output is 27x larger than the default
+    # config's (0.45 vs 0.017 abs-max): the absolute 1e-4 gate of the default
+    # configuration scales with it for the f16 operands
+    assert error < max(GATE[dtype], 5e-4 * scale if dtype == 'f16' else 0.)
 
 
 @pytest.mark.parametrize('method,threshold', [
@@ -405,6 +409,48 @@ def test_mel(device):
         audio.to(device), mels=True,
         log_dynamic_range_compression_threshold=-1.)
     assert max_abs(clamped, torch.clamp(want, min=-1.)) < 1e-4
+
+
+def test_spectrogram_backward(device):
+    """The training mel loss differentiates through spectrogram.from_audio
+    (promonet/train/core.py:277-305): gradients of the HIP path (framed-DFT
+    adjoint on the exact-fp32 MFMA kernel) against torch autograd through the
+    oracle's torch.stft restatement, linear and mel, ragged length."""
+    import promonet_amd
+    gen = torch.Generator().manual_seed(11)
+    for batch, samples, mels in ((2, 256 * 24, False), (1, 256 * 9 + 100, False),
+                                 (3, 256 * 31, True)):
+        audio = torch.randn(batch, 1, samples, generator=gen) * .1
+        frames = samples // 256
+        weight = torch.randn(
+            batch, 80 if mels else 513, frames, generator=gen).squeeze(0)
+        reference = audio.clone().requires_grad_(True)
+        (oracle.spectrogram(reference, mels=mels) * weight).sum().backward()
+        ours = audio.clone().to(device).requires_grad_(True)
+        spec = promonet_amd.preprocess.spectrogram.from_audio(ours, mels)
+        assert spec.requires_grad
+        (spec * weight.to(device)).sum().backward()
+        assert ours.grad.shape == reference.grad.shape
+        error = max_abs(ours.grad, reference.grad)
+        scale = reference.grad.abs().max().item()
+        print(f'spectrogram backward {batch}x{samples} mels={mels}: '
+              f'max-abs {error:.3e} (grad abs-max {scale:.3e})')
+        assert error < 2e-5 * max(1., scale)
+    # mel alone, clamp active on part of the tensor
+    spec = (torch.rand(2, 513, 12, generator=gen) + .01)
+    weight = torch.randn(2, 80, 12, generator=gen)
+    reference = spec.clone().requires_grad_(True)
+    (oracle.linear_to_mel(reference, threshold=-2.) * weight).sum().backward()
+    ours = spec.clone().to(device).requires_grad_(True)
+    out = promonet_amd.preprocess.spectrogram.linear_to_mel(ours, -2.)
+    (out * weight.to(device)).sum().backward()
+    assert max_abs(ours.grad, reference.grad) < 1e-4 * max(
+        1., reference.grad.abs().max().item())
+    # no graph is kept (and nothing extra allocated) under inference mode
+    with torch.inference_mode():
+        plain = promonet_amd.preprocess.spectrogram.from_audio(
+            audio.to(device), True)
+    assert not plain.requires_grad
 
 
 def test_loudness(device):
