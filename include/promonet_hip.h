@@ -231,6 +231,14 @@ int pm_to_channels_last(const float* src, float* dst, int batch, int channels,
 int pm_grid_sample(const float* seq, const float* grid, float* out, int rows,
                    int n_in, int n_out, int mode, float scale, float offset,
                    float lo, float hi, void* stream);
+/* Selective time-stretch grid (edit/core.py:57-110, stretch_unvoiced /
+ * stretch_silence off): ppg (P, frames), `indices` (n) = rows of the phonemes
+ * that ARE stretched (device int32); writes selected (frames) = their summed
+ * probability and grid (target_frames), the reference's sequential fp32
+ * recurrence whose step follows that probability.                          */
+int pm_stretch_grid(const float* ppg, const int* indices, int n_indices,
+                    float* selected, float* grid, int frames,
+                    int target_frames, void* stream);
 
 /* ---- FARGAN vocoder engine: replaces promonet.model.FARGAN ---------------
  * (promonet/model/fargan.py, selected by config/fargan.py MODEL = 'fargan').
@@ -256,6 +264,16 @@ int pm_fargan_forward(pm_fargan_t h, const float* features, int features_cl,
                       const float* previous_samples, int previous_batch,
                       float* out, int batch, int frames, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* Ragged batch (lengths (B) int32 frames on the device): the model is causal,
+ * so out[b, :256 lengths[b]] equals utterance b synthesised alone, bit for
+ * bit; the tail is zeros.                                                  */
+int pm_fargan_forward_ragged(pm_fargan_t h, const float* features,
+                             int features_channels_last,
+                             const float* global_features, int global_batch,
+                             const float* previous_samples, int previous_batch,
+                             const int* lengths, float* out, int batch,
+                             int frames, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* Kernel selection: 0 auto (clusters of 8 workgroups per utterance up to 160
  * utterances per launch, else one persistent workgroup per utterance),

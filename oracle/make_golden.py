@@ -91,6 +91,44 @@ def run(which):
         torch.save(golden, GOLDEN / 'generator_fargan.pt')
         return
 
+    if which == 'edit_voiced':
+        # Selective time-stretch (edit/core.py:57-110): the REAL reference loop
+        # over the restated phoneme inventory (third-party constants, see
+        # reference_import). PPG rows follow that inventory's order.
+        frames = 61
+        inputs = oracle.synthetic_inputs(1, frames, seed=19)
+        loud, pit, per, pg = (
+            inputs[0][0], inputs[1], inputs[2], inputs[3][0])
+        cases = []
+        for ratio, unvoiced, silence, cents in (
+            (1.4, False, True, None), (.7, False, False, 300.),
+            (1.15, False, False, None)
+        ):
+            # (stretch_unvoiced=True, stretch_silence=False) cannot be pinned:
+            # the reference extends its index list with phoneme STRINGS there
+            # (edit/core.py:69-76) and torch.tensor(indices) raises
+            result = promonet.edit.from_features(
+                loud.clone(), pit.clone(), per.clone(), pg.clone(), cents,
+                ratio, None, unvoiced, silence, return_grid=True)
+            mine = oracle.edit_from_features(
+                loud.clone(), pit.clone(), per.clone(), pg.clone(), cents,
+                ratio, None, None, unvoiced, silence)
+            mine_grid = oracle.grid_selective(
+                pg, ratio, oracle.stretched_phonemes(unvoiced, silence))
+            error = (mine_grid - result[4]).abs().max().item()
+            print(f'edit_voiced ratio {ratio}: grid vs reference {error:.3e}')
+            assert error < 1e-4
+            for a, b in zip(result[:4], mine):
+                assert a.shape == b.shape and (a - b).abs().max() < 1e-3
+            cases.append({
+                'time_stretch_ratio': ratio, 'stretch_unvoiced': unvoiced,
+                'stretch_silence': silence, 'pitch_shift_cents': cents,
+                'grid': result[4].clone(),
+                'outputs': tuple(t.clone() for t in result[:4])})
+        torch.save({'frames': frames, 'input_seed': 19, 'cases': cases},
+                   GOLDEN / 'edit_voiced.pt')
+        return
+
     if which in ('zero_shot', 'sparse_none'):
         assert promonet.HIFIGAN_UPSAMPLE_INITIAL_SIZE == 32
         model = promonet.model.Generator().eval()
@@ -291,7 +329,7 @@ if __name__ == '__main__':
         run(sys.argv[1])
     else:
         for which in ('small', 'default', 'fargan', 'zero_shot',
-                      'sparse_none'):
+                      'sparse_none', 'edit_voiced'):
             subprocess.run(
                 [sys.executable, __file__, which], check=True)
         for file in sorted(GOLDEN.iterdir()):

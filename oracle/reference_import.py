@@ -128,11 +128,18 @@ def _install_stubs(config_files):
         setattr(torchutil, name, mock.MagicMock())
         sys.modules[f'torchutil.{name}'] = getattr(torchutil, name)
 
+    import restatement
     ppgs = module(
         'ppgs',
         REPRESENTATION_KIND='ppg',
         SIMILARITY_EXPONENT=1.2,
-        PHONEMES=[f'p{i}' for i in range(40)],
+        # explicit phoneme inventory (the restated third-party constants) so
+        # that the reference's selective time-stretch loop (edit/core.py:57-110)
+        # can run for the goldens
+        PHONEMES=list(restatement.PHONEMES),
+        VOICED=list(restatement.VOICED),
+        PHONEME_TO_INDEX_MAPPING={
+            p: i for i, p in enumerate(restatement.PHONEMES)},
         sparsify=_sparsify,
         representation_file_extension=lambda: 'ppg')
     for name in ('edit', 'load', 'preprocess', 'plot', 'data'):
@@ -147,10 +154,14 @@ def _install_stubs(config_files):
         tensor, round(tensor.shape[-1] / ratio + 1e-4))
     ppgs.from_audio = mock.MagicMock()
     ppgs.distance = mock.MagicMock()
+    # pypar: only the silence token is read on this path (edit/core.py:66,74)
+    pypar = mock.MagicMock(name='pypar')
+    pypar.SILENCE = restatement.SILENCE
+    sys.modules['pypar'] = pypar
 
     # Everything else: any (sub)module of these top-level names is a mock
     mocked = {
-        'penn', 'librosa', 'torchaudio', 'pypar', 'pyworld', 'resampy',
+        'penn', 'librosa', 'torchaudio', 'pyworld', 'resampy',
         'soundfile', 'jiwer', 'umap', 'torbi', 'whisper', 'vocos',
         'transformers', 'matplotlib', 'pysodic', 'pyfoal', 'pyloudnorm',
         'torchcrepe', 'encodec', 'g2p_en', 'huggingface_hub'}

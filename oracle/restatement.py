@@ -749,14 +749,69 @@ def grid_constant(tensor, ratio):
     return grid_of_length(tensor, round(tensor.shape[-1] / ratio + 1e-4))
 
 
+# Phoneme inventory behind the selective time-stretch (third-party ppgs /
+# pypar constants read at edit/core.py:57-76; PARITY UNPINNED - restated)
+PHONEMES = [
+    'aa', 'ae', 'ah', 'ao', 'aw', 'ay', 'b', 'ch', 'd', 'dh', 'eh', 'er', 'ey',
+    'f', 'g', 'hh', 'ih', 'iy', 'jh', 'k', 'l', 'm', 'n', 'ng', 'ow', 'oy', 'p',
+    'r', 's', 'sh', 't', 'th', 'uh', 'uw', 'v', 'w', 'y', 'z', 'zh', '<silent>']
+VOICED = [
+    'aa', 'ae', 'ah', 'ao', 'aw', 'ay', 'b', 'd', 'dh', 'eh', 'er', 'ey', 'g',
+    'ih', 'iy', 'jh', 'l', 'm', 'n', 'ng', 'ow', 'oy', 'r', 'uh', 'uw', 'v',
+    'w', 'y', 'z', 'zh']
+SILENCE = '<silent>'
+
+
+def stretched_phonemes(stretch_unvoiced, stretch_silence):
+    """edit/core.py:57-76: indices of the phonemes that are stretched."""
+    index = {p: i for i, p in enumerate(PHONEMES)}
+    indices = [index[p] for p in VOICED]
+    if stretch_silence:
+        indices.append(index[SILENCE])
+    if stretch_unvoiced:
+        indices.extend(list(
+            index[p] for p in PHONEMES if p not in VOICED and p != SILENCE))
+    return indices
+
+
+def grid_selective(ppg, ratio, indices):
+    """edit/core.py:77-110: the sequential recurrence, in float32 like the
+    reference (whose loop variables are 0-dim float32 tensors from the first
+    step on)."""
+    selected = ppg[torch.tensor(indices)].sum(dim=0)
+    target = round(ppg.shape[-1] / ratio)
+    total = selected.sum()
+    effective = (target - (ppg.shape[-1] - total)) / total
+    grid = torch.zeros(target)
+    i = torch.zeros(())
+    for j in range(1, target):
+        left = min(int(math.floor(i)), len(selected) - 1)
+        if left + 1 < len(selected):
+            offset = i - left
+            probability = offset * selected[left + 1] + \
+                (1 - offset) * selected[left]
+        else:
+            probability = selected[left]
+        step = 1. / (probability * effective + (1 - probability))
+        grid[j] = grid[j - 1] + step
+        i = i + step
+    return grid
+
+
 def edit_from_features(
     loudness, pitch, periodicity, ppg, pitch_shift_cents=None,
-    time_stretch_ratio=None, loudness_scale_db=None, grid=None
+    time_stretch_ratio=None, loudness_scale_db=None, grid=None,
+    stretch_unvoiced=True, stretch_silence=True
 ):
-    """edit/core.py:17-132 with stretch_unvoiced = stretch_silence = True."""
+    """edit/core.py:17-132."""
     if time_stretch_ratio is not None:
         if grid is None:
-            grid = grid_constant(ppg, time_stretch_ratio)
+            if stretch_unvoiced and stretch_silence:
+                grid = grid_constant(ppg, time_stretch_ratio)
+            else:
+                grid = grid_selective(
+                    ppg, time_stretch_ratio,
+                    stretched_phonemes(stretch_unvoiced, stretch_silence))
         pitch = 2 ** grid_sample(torch.log2(pitch), grid)
         periodicity = grid_sample(periodicity, grid)
         loudness = grid_sample(loudness, grid)

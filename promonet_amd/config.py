@@ -39,6 +39,19 @@ VARIABLE_PITCH_BINS = True
 VITERBI_DECODE_PITCH = True
 INPUT_FEATURES = ['loudness', 'pitch', 'periodicity', 'ppg']
 
+# Phoneme inventory of the PPGs (third-party `ppgs` package: PHONEMES, VOICED;
+# `pypar.SILENCE`), read by the selective time-stretch of promonet.edit
+# (edit/core.py:57-80). Restated from the published packages - parity unpinned.
+PHONEMES = [
+    'aa', 'ae', 'ah', 'ao', 'aw', 'ay', 'b', 'ch', 'd', 'dh', 'eh', 'er', 'ey',
+    'f', 'g', 'hh', 'ih', 'iy', 'jh', 'k', 'l', 'm', 'n', 'ng', 'ow', 'oy', 'p',
+    'r', 's', 'sh', 't', 'th', 'uh', 'uw', 'v', 'w', 'y', 'z', 'zh', '<silent>']
+VOICED = [
+    'aa', 'ae', 'ah', 'ao', 'aw', 'ay', 'b', 'd', 'dh', 'eh', 'er', 'ey', 'g',
+    'ih', 'iy', 'jh', 'l', 'm', 'n', 'ng', 'ow', 'oy', 'r', 'uh', 'uw', 'v',
+    'w', 'y', 'z', 'zh']
+SILENCE = '<silent>'
+
 # Model parameters (defaults.py:213-289)
 LRELU_SLOPE = .1
 MODEL = 'hifigan'

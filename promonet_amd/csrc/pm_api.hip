@@ -1380,6 +1380,28 @@ extern "C" int pm_grid_sample(
     return PM_OK;
 }
 
+// Selective time-stretch grid (edit/core.py:57-110)
+extern "C" int pm_stretch_grid(
+    const float* ppg, const int* indices, int n_indices, float* selected,
+    float* grid, int frames, int target_frames, void* stream) {
+    if (!ppg || !indices || !selected || !grid)
+        return fail(PM_EINVAL, "null argument");
+    if (n_indices < 1 || frames < 1 || target_frames < 1)
+        return fail(PM_EINVAL, "bad stretch-grid arguments");
+    StretchArgs a;
+    a.ppg = ppg; a.indices = indices; a.selected = selected; a.grid = grid;
+    a.n = n_indices; a.T = frames; a.target = target_frames;
+    const size_t bytes = (size_t)frames * sizeof(float);
+    const size_t smem = bytes <= 64 * 1024 ? bytes : 0;
+    auto kern = pm_stretch_grid_kernel;
+    if (smem > 48 * 1024)
+        HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern),
+                                      (int)smem));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(256), smem, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
 // ---------------------------------------------------------------------------
 // FARGAN engine (config/fargan.py): replaces promonet.model.FARGAN
 // ---------------------------------------------------------------------------
@@ -1389,14 +1411,15 @@ struct FLayer {
     bool normed;         // weight-normed Linear: accepts weight_g + weight_v
     int rows, cols, rpad, kpad;
     int kw = 0;              // > 0: also packed K-split, 8 x (rpad x kw)
-    void* packed = nullptr;
-    void* packed_k = nullptr;
+    size_t offset = 0;       // element offsets into the one weight buffer
+    size_t offset_k = 0;
     float* tmp_g = nullptr;
     float* tmp_v = nullptr;
     bool has = false;
 };
 
 struct pm_fargan_s {
+    void* weights = nullptr;   // every packed layer (FarganWeights layout)
     int nfeat, G, dtype;
     int mode = 0;        // 0 auto, 1 one workgroup per utterance, 2 clusters
     std::vector<FLayer> layers;
@@ -1430,6 +1453,18 @@ static std::vector<FLayer> fargan_layers(int nin) {
     l[4].kw = 32;                                   // framewise conv GLU gate
     l[11].kw = l[12].kw = l[13].kw = 32;            // GRU GLU gates
     l[16].kw = 32;                                  // output layer
+    // offsets = FarganWeights<>: row-packed layers in table order, then the
+    // K-split copies
+    size_t at = 0;
+    for (auto& layer : l) {
+        layer.offset = at;
+        at += (size_t)layer.rpad * layer.kpad;
+    }
+    for (auto& layer : l)
+        if (layer.kw) {
+            layer.offset_k = at;
+            at += (size_t)FG_G * layer.rpad * layer.kw;
+        }
     return l;
 }
 
@@ -1446,15 +1481,33 @@ extern "C" int pm_fargan_create(
     auto* h = new pm_fargan_s();
     h->nfeat = num_features; h->G = global_channels; h->dtype = weight_dtype;
     h->layers = fargan_layers(num_features + global_channels);
+    typedef FarganWeights<float> W;
+    const auto& l = h->layers;
+    if (l[0].offset != W::COND0 || l[1].offset != W::COND1 ||
+        l[2].offset != W::COND2 || l[3].offset != W::FWCONV ||
+        l[4].offset != W::FWGLU || l[5].offset != W::GRU_IH ||
+        l[8].offset != W::GRU_HH || l[11].offset != W::GRU_GLU ||
+        l[14].offset != W::SKIP || l[15].offset != W::SKIP_GLU ||
+        l[16].offset != W::OUT || l[1].offset_k != W::K_COND1 ||
+        l[4].offset_k != W::K_FWGLU || l[11].offset_k != W::K_GRU_GLU ||
+        l[16].offset_k != W::K_OUT) {
+        delete h;
+        return fail(PM_ESTATE, "FARGAN layer table and FarganWeights disagree");
+    }
+    const size_t esize = weight_dtype == PM_F32 ? 4 : 2;
+    hipError_t e = hipMalloc(&h->weights, W::TOTAL * esize);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(PM_EHIP, "hipMalloc: %s", hipGetErrorString(e));
+    }
     *out = h;
     return PM_OK;
 }
 
 extern "C" int pm_fargan_destroy(pm_fargan_t h) {
     if (!h) return PM_OK;
+    if (h->weights) hipFree(h->weights);
     for (auto& l : h->layers) {
-        if (l.packed) hipFree(l.packed);
-        if (l.packed_k) hipFree(l.packed_k);
         if (l.tmp_g) hipFree(l.tmp_g);
         if (l.tmp_v) hipFree(l.tmp_v);
     }
@@ -1464,33 +1517,29 @@ extern "C" int pm_fargan_destroy(pm_fargan_t h) {
 
 template <class WT>
 static hipError_t fargan_pack_t(
-    FLayer& l, const float* w, size_t esize, hipStream_t s) {
+    pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) {
     const int gru = l.rows == 768 ? 1 : 0;   // gate-interleaved GRU rows
     const size_t elems = (size_t)l.rpad * l.kpad;
-    hipError_t e;
-    if (!l.packed && (e = hipMalloc(&l.packed, elems * esize)) != hipSuccess)
-        return e;
+    WT* base = (WT*)h->weights;
     hipLaunchKernelGGL(pm_fargan_pack_kernel<WT>,
                        dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s,
-                       w, (WT*)l.packed, l.rows, l.cols, l.rpad, l.kpad, gru, 0);
+                       w, base + l.offset, l.rows, l.cols, l.rpad, l.kpad, gru,
+                       0);
     if (l.kw) {
         // K-split copy: member g's sub-matrix W[:, g kw : (g + 1) kw]
         const size_t sub = (size_t)l.rpad * l.kw;
-        if (!l.packed_k &&
-            (e = hipMalloc(&l.packed_k, FG_G * sub * esize)) != hipSuccess)
-            return e;
         for (int g = 0; g < FG_G; ++g)
             hipLaunchKernelGGL(pm_fargan_pack_kernel<WT>,
                                dim3((unsigned)((sub + 255) / 256)), dim3(256),
-                               0, s, w, (WT*)l.packed_k + g * sub, l.rows,
+                               0, s, w, base + l.offset_k + g * sub, l.rows,
                                l.cols, l.rpad, l.kw, 0, g * l.kw);
     }
     return hipGetLastError();
 }
 
 static int fargan_pack(pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) {
-    if (h->dtype == PM_F32) HIP_TRY(fargan_pack_t<float>(l, w, 4, s));
-    else HIP_TRY(fargan_pack_t<_Float16>(l, w, 2, s));
+    if (h->dtype == PM_F32) HIP_TRY(fargan_pack_t<float>(h, l, w, s));
+    else HIP_TRY(fargan_pack_t<_Float16>(h, l, w, s));
     l.has = true;
     return PM_OK;
 }
@@ -1618,25 +1667,17 @@ template <class WT>
 static int fargan_launch(
     pm_fargan_t h, const FarganArgs& a, hipStream_t s, void* cluster_state) {
     FarganWeights<WT> w;
-    auto P = [&](int i) { return (const WT*)h->layers[i].packed; };
-    w.cond[0] = P(0); w.cond[1] = P(1); w.cond[2] = P(2);
-    w.fwconv = P(3); w.fwconv_glu = P(4);
-    for (int n = 0; n < 3; ++n) {
-        w.gru_ih[n] = P(5 + n); w.gru_hh[n] = P(8 + n); w.gru_glu[n] = P(11 + n);
-    }
-    w.skip = P(14); w.skip_glu = P(15); w.out = P(16);
+    w.base = (const WT*)h->weights;
     if (cluster_state) {
-        FarganSplitWeights<WT> ws;
-        auto K = [&](int i) { return (const WT*)h->layers[i].packed_k; };
-        ws.cond1 = K(1); ws.fwconv_glu = K(4);
-        for (int n = 0; n < 3; ++n) ws.gru_glu[n] = K(11 + n);
-        ws.out = K(16);
         // counters / payload / error word are re-initialised on every call
         HIP_TRY(hipMemsetAsync(cluster_state, 0, fargan_state_bytes(), s));
         FarganClusterArgs ca;
         ca.f = a;
         ca.state = (unsigned*)cluster_state;
         ca.error = ca.state + (size_t)FG_MAX_CLUSTERS * FG_CSTATE;
+#ifdef PM_TUNING
+        ca.timeline = g_timeline;
+#endif
         // U utterances per cluster in lockstep: 1 while one cluster per
         // utterance fits the resident grid (32 clusters = 256 CUs), then 2,
         // then 4; beyond that the clusters walk the batch in waves
@@ -1652,7 +1693,7 @@ static int fargan_launch(
             hipError_t e = pm_ensure_dynamic_lds(
                 reinterpret_cast<const void*>(kern), (int)smem);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, block, smem, s, ca, w, ws);
+            hipLaunchKernelGGL(kern, grid, block, smem, s, ca, w);
             return hipGetLastError();
         };
         hipError_t e = U == 1 ? launch(pm_fargan_cluster_kernel<WT, 1>)
@@ -1686,10 +1727,10 @@ extern "C" int pm_fargan_check(
 // FARGAN.forward (model/fargan.py:21-59): features (B, nfeat + 1, T) with the
 // pitch period as last channel (or channels-last (B, T, pad32(nfeat + 1)) when
 // features_cl != 0), global (Bg, G), previous (Bp, 512) or NULL -> (B, 1, 256 T)
-extern "C" int pm_fargan_forward(
+static int fargan_forward_impl(
     pm_fargan_t h, const float* features, int features_cl, const float* g,
-    int gbatch, const float* previous, int pbatch, float* out, int B, int T,
-    void* ws, size_t ws_bytes, void* stream) {
+    int gbatch, const float* previous, int pbatch, const int* lengths,
+    float* out, int B, int T, void* ws, size_t ws_bytes, void* stream) {
     if (!h || !features || !g || !out) return fail(PM_EINVAL, "null argument");
     if (!h->finalized) return fail(PM_ESTATE, "pm_fargan_finalize not called");
     if (B < 1 || T < 1) return fail(PM_EINVAL, "empty batch or sequence");
@@ -1714,6 +1755,27 @@ extern "C" int pm_fargan_forward(
     a.features_cl = fcl; a.global = g; a.previous = previous; a.out = out;
     a.B = B; a.T = T; a.cstride = cpad; a.nfeat = h->nfeat; a.G = h->G;
     a.global_batch = gbatch; a.previous_batch = pbatch;
+    a.lengths = lengths;
     return h->dtype == PM_F32 ? fargan_launch<float>(h, a, s, cluster_state)
                               : fargan_launch<_Float16>(h, a, s, cluster_state);
+}
+
+extern "C" int pm_fargan_forward(
+    pm_fargan_t h, const float* features, int features_cl, const float* g,
+    int gbatch, const float* previous, int pbatch, float* out, int B, int T,
+    void* ws, size_t ws_bytes, void* stream) {
+    return fargan_forward_impl(h, features, features_cl, g, gbatch, previous,
+                               pbatch, nullptr, out, B, T, ws, ws_bytes, stream);
+}
+
+// Ragged batch: utterance b is lengths[b] <= T frames long inside the padded
+// tensors. FARGAN is causal (frame t reads features <= t only), so the valid
+// prefix equals the stand-alone synthesis bit for bit; the tail is zeros.
+extern "C" int pm_fargan_forward_ragged(
+    pm_fargan_t h, const float* features, int features_cl, const float* g,
+    int gbatch, const float* previous, int pbatch, const int* lengths,
+    float* out, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!lengths) return fail(PM_EINVAL, "null lengths");
+    return fargan_forward_impl(h, features, features_cl, g, gbatch, previous,
+                               pbatch, lengths, out, B, T, ws, ws_bytes, stream);
 }

@@ -270,7 +270,7 @@ __host__ __device__ constexpr int pair_smem_bytes(int d) {
 #define PM_PAIR_MINWAVES4 1
 #endif
 #ifndef PM_BLOCK_MINWAVES4
-#define PM_BLOCK_MINWAVES4 1
+#define PM_BLOCK_MINWAVES4 2
 #endif
 template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS>
 __global__ __launch_bounds__(WM * WN * 64,

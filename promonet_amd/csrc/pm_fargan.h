@@ -25,6 +25,8 @@
 #define FG_SUBIN 260          // 128 features + 64 previous + 68 lookback
 #define FG_SKIP 1152
 
+// Dot products are written as explicit fma chains in a fixed order so that
+// every instantiation (kernel variant, utterances in lockstep) rounds alike.
 template <class WT> struct FgVec;
 template <> struct FgVec<float> {
     static constexpr int VEC = 4;
@@ -35,19 +37,19 @@ template <> struct FgVec<float> {
     __device__ static __forceinline__ float dotf(
         const float (&f)[4], const float* x) {
         const float4 b = *reinterpret_cast<const float4*>(x);
-        return f[0] * b.x + f[1] * b.y + f[2] * b.z + f[3] * b.w;
+        return fmaf(f[3], b.w, fmaf(f[2], b.z, fmaf(f[1], b.y, f[0] * b.x)));
     }
     __device__ static __forceinline__ float dot(
         const float* __restrict__ w, const float* x) {
-        const float4 a = *reinterpret_cast<const float4*>(w);
-        const float4 b = *reinterpret_cast<const float4*>(x);
-        return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        float f[4];
+        unpack(*reinterpret_cast<const uint4*>(w), f);
+        return dotf(f, x);
     }
 };
 template <> struct FgVec<_Float16> {
     static constexpr int VEC = 8;
     // 16 weight bytes already in registers -> fp32 once, then one dot per
-    // utterance (same product order as dot())
+    // utterance
     __device__ static __forceinline__ void unpack(uint4 wv, float (&f)[8]) {
         const half8 a = __builtin_bit_cast(half8, wv);
 #pragma unroll
@@ -57,17 +59,16 @@ template <> struct FgVec<_Float16> {
         const float (&f)[8], const float* x) {
         const float4 b0 = *reinterpret_cast<const float4*>(x);
         const float4 b1 = *reinterpret_cast<const float4*>(x + 4);
-        return f[0] * b0.x + f[1] * b0.y + f[2] * b0.z + f[3] * b0.w +
-               f[4] * b1.x + f[5] * b1.y + f[6] * b1.z + f[7] * b1.w;
+        float d = f[0] * b0.x;
+        d = fmaf(f[1], b0.y, d); d = fmaf(f[2], b0.z, d); d = fmaf(f[3], b0.w, d);
+        d = fmaf(f[4], b1.x, d); d = fmaf(f[5], b1.y, d); d = fmaf(f[6], b1.z, d);
+        return fmaf(f[7], b1.w, d);
     }
     __device__ static __forceinline__ float dot(
         const _Float16* __restrict__ w, const float* x) {
-        const half8 a = *reinterpret_cast<const half8*>(w);
-        const float4 b0 = *reinterpret_cast<const float4*>(x);
-        const float4 b1 = *reinterpret_cast<const float4*>(x + 4);
-        return (float)a[0] * b0.x + (float)a[1] * b0.y + (float)a[2] * b0.z +
-               (float)a[3] * b0.w + (float)a[4] * b1.x + (float)a[5] * b1.y +
-               (float)a[6] * b1.z + (float)a[7] * b1.w;
+        float f[8];
+        unpack(*reinterpret_cast<const uint4*>(w), f);
+        return dotf(f, x);
     }
 };
 
@@ -124,17 +125,61 @@ __global__ __launch_bounds__(256) void pm_fargan_pack_kernel(
                                              : 0.f);
 }
 
+// All packed layers live in ONE buffer at compile-time offsets (elements), so
+// a kernel carries a single base pointer: with one pointer per layer the 23
+// of them exhausted the scalar registers and spilled into vector registers.
+// Order = the layer table of pm_api.hip (fargan_layers); the K-split copies
+// used by the cluster kernel follow the row-packed layers.
 template <class WT>
 struct FarganWeights {
-    const WT* cond[3];        // 384x372, 384x372, 512x372 (padded)
-    const WT* fwconv;         // 256 x 520
-    const WT* fwconv_glu;     // 256 x 256
-    const WT* gru_ih[3];      // 768 x 384
-    const WT* gru_hh[3];      // 768 x 256
-    const WT* gru_glu[3];     // 256 x 256
-    const WT* skip;           // 256 x 1152
-    const WT* skip_glu;       // 256 x 256
-    const WT* out;            // 64 x 256
+    const WT* base;
+    static constexpr size_t COND0 = 0;                         // 384 x 376
+    static constexpr size_t COND1 = COND0 + 384 * 376;         // 384 x 376
+    static constexpr size_t COND2 = COND1 + 384 * 376;         // 512 x 376
+    static constexpr size_t FWCONV = COND2 + 512 * 376;        // 256 x 520
+    static constexpr size_t FWGLU = FWCONV + 256 * 520;        // 256 x 256
+    static constexpr size_t GRU_IH = FWGLU + 256 * 256;        // 3 x 768 x 384
+    static constexpr size_t GRU_HH = GRU_IH + 3 * 768 * 384;   // 3 x 768 x 256
+    static constexpr size_t GRU_GLU = GRU_HH + 3 * 768 * 256;  // 3 x 256 x 256
+    static constexpr size_t SKIP = GRU_GLU + 3 * 256 * 256;    // 256 x 1152
+    static constexpr size_t SKIP_GLU = SKIP + 256 * 1152;      // 256 x 256
+    static constexpr size_t OUT = SKIP_GLU + 256 * 256;        // 64 x 256
+    // K-split copies: member g's (R x K / 8) sub-matrix, 8 back to back
+    static constexpr size_t K_COND1 = OUT + 64 * 256;          // 8 x 384 x 48
+    static constexpr size_t K_FWGLU = K_COND1 + 8 * 384 * 48;  // 8 x 256 x 32
+    static constexpr size_t K_GRU_GLU = K_FWGLU + 8 * 256 * 32;    // 3 x 8 x 256 x 32
+    static constexpr size_t K_OUT = K_GRU_GLU + 3 * 8 * 256 * 32;  // 8 x 64 x 32
+    static constexpr size_t TOTAL = K_OUT + 8 * 64 * 32;
+    __device__ __forceinline__ const WT* cond(int i) const {
+        return base + (i == 0 ? COND0 : i == 1 ? COND1 : COND2);
+    }
+    __device__ __forceinline__ const WT* fwconv() const { return base + FWCONV; }
+    __device__ __forceinline__ const WT* fwconv_glu() const { return base + FWGLU; }
+    __device__ __forceinline__ const WT* gru_ih(int n) const {
+        return base + GRU_IH + (size_t)n * (768 * 384);
+    }
+    __device__ __forceinline__ const WT* gru_hh(int n) const {
+        return base + GRU_HH + (size_t)n * (768 * 256);
+    }
+    __device__ __forceinline__ const WT* gru_glu(int n) const {
+        return base + GRU_GLU + (size_t)n * (256 * 256);
+    }
+    __device__ __forceinline__ const WT* skip() const { return base + SKIP; }
+    __device__ __forceinline__ const WT* skip_glu() const { return base + SKIP_GLU; }
+    __device__ __forceinline__ const WT* out() const { return base + OUT; }
+    // K-split sub-matrix of member g
+    __device__ __forceinline__ const WT* k_cond1(int g) const {
+        return base + K_COND1 + (size_t)g * (384 * 48);
+    }
+    __device__ __forceinline__ const WT* k_fwconv_glu(int g) const {
+        return base + K_FWGLU + (size_t)g * (256 * 32);
+    }
+    __device__ __forceinline__ const WT* k_gru_glu(int n, int g) const {
+        return base + K_GRU_GLU + (size_t)(n * 8 + g) * (256 * 32);
+    }
+    __device__ __forceinline__ const WT* k_out(int g) const {
+        return base + K_OUT + (size_t)g * (64 * 32);
+    }
 };
 
 struct FarganArgs {
@@ -144,6 +189,9 @@ struct FarganArgs {
     float* out;                 // (B, 256 T)
     int B, T, cstride, nfeat, G;
     int global_batch, previous_batch;
+    const int* lengths;         // (B) valid frames per utterance or null: the
+                                // model is causal, so a zero-padded utterance
+                                // simply stops early; its tail is zero-filled
 };
 
 __device__ __forceinline__ float fg_sigmoid(float v) {
@@ -168,13 +216,15 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
     __shared__ float prev[FG_PREV];
     __shared__ int s_period;
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;   // re-laundered per step (see the cluster kernel)
     const int b = blockIdx.x;
-    const int T = a.T;
-    const float* feat = a.features_cl + (size_t)b * T * a.cstride;
+    const int T = a.lengths ? min(max(a.lengths[b], 0), a.T) : a.T;
+    for (int i = T * FG_HOP + tid; i < a.T * FG_HOP; i += NT)
+        a.out[(size_t)b * a.T * FG_HOP + i] = 0.f;
+    const float* feat = a.features_cl + (size_t)b * a.T * a.cstride;
     const float* glob =
         a.global + (size_t)(a.global_batch == 1 ? 0 : b) * a.G;
-    float* out = a.out + (size_t)b * T * FG_HOP;
+    float* out = a.out + (size_t)b * a.T * FG_HOP;
     const int nin = a.nfeat + a.G;   // 371
 
     // ---- initial recurrent state (fargan.py:406-415) ----
@@ -197,22 +247,23 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
         if (tid == 0) s_period = (int)rintf(row[a.nfeat]);   // fargan.py:94
         __syncthreads();
         {
-            part[tid] = fg_gemv<WT, 384, 2>(w.cond[0], condin, condin, CPAD, CPAD, tid);
+            part[tid] = fg_gemv<WT, 384, 2>(w.cond(0), condin, condin, CPAD, CPAD, tid);
             __syncthreads();
             if (tid < nin) c1[tid] = tanhf(part[tid] + part[tid + 384]);
             __syncthreads();
-            part[tid] = fg_gemv<WT, 384, 2>(w.cond[1], c1, c1, CPAD, CPAD, tid);
+            part[tid] = fg_gemv<WT, 384, 2>(w.cond(1), c1, c1, CPAD, CPAD, tid);
             __syncthreads();
             if (tid < nin) c2[tid] = tanhf(part[tid] + part[tid + 384]);
             __syncthreads();
             if (tid < 512)
-                cond[tid] = tanhf(fg_gemv<WT, 512, 1>(w.cond[2], c2, c2, CPAD, CPAD, tid));
+                cond[tid] = tanhf(fg_gemv<WT, 512, 1>(w.cond(2), c2, c2, CPAD, CPAD, tid));
             __syncthreads();
         }
         const int period = s_period;
 
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {
+            asm volatile("" : "+v"(tid));
             // ---- sub-frame inputs (fargan.py:233-256) ----
             if (tid < 128) {
                 subin[tid] = cond[4 * tid + s];          // reshape/permute :109
@@ -233,11 +284,11 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
             __syncthreads();
 
             // ---- framewise conv: Linear(520 -> 256), tanh, GLU (:349-372) ----
-            part[tid] = fg_gemv<WT, 256, 3>(w.fwconv, subin, subin, 520, 520, tid);
+            part[tid] = fg_gemv<WT, 256, 3>(w.fwconv(), subin, subin, 520, 520, tid);
             __syncthreads();
             if (tid < 256) f1[tid] = tanhf(part[tid] + part[tid + 256] + part[tid + 512]);
             __syncthreads();
-            part[tid] = fg_gemv<WT, 256, 3>(w.fwconv_glu, f1, f1, 256, 256, tid);
+            part[tid] = fg_gemv<WT, 256, 3>(w.fwconv_glu(), f1, f1, 256, 256, tid);
             __syncthreads();
             if (tid < 256)
                 skipbuf[768 + tid] = f1[tid] * fg_sigmoid(
@@ -251,9 +302,9 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
                 // or the previous GLU output
                 const float* xa = n == 0 ? skipbuf + 768 : skipbuf + (n - 1) * 256;
                 part[tid] = fg_gemv<WT, 768, 1>(
-                    w.gru_ih[n], xa, skipbuf + 1024, 256, 384, tid);
+                    w.gru_ih(n), xa, skipbuf + 1024, 256, 384, tid);
                 part2[tid] = fg_gemv<WT, 768, 1>(
-                    w.gru_hh[n], hid[n], hid[n], 256, 256, tid);
+                    w.gru_hh(n), hid[n], hid[n], 256, 256, tid);
                 __syncthreads();
                 if (tid < 256) {
                     const int ir = fg_gru_row(0, tid), iz = fg_gru_row(1, tid);
@@ -264,7 +315,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
                     hid[n][tid] = (1.f - z) * nn + z * hid[n][tid];
                 }
                 __syncthreads();
-                part[tid] = fg_gemv<WT, 256, 3>(w.gru_glu[n], hid[n], hid[n], 256, 256, tid);
+                part[tid] = fg_gemv<WT, 256, 3>(w.gru_glu(n), hid[n], hid[n], 256, 256, tid);
                 __syncthreads();
                 if (tid < 256)
                     skipbuf[n * 256 + tid] = hid[n][tid] * fg_sigmoid(
@@ -273,17 +324,17 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
             }
 
             // ---- skip connection + output layer (:317-333) ----
-            part[tid] = fg_gemv<WT, 256, 3>(w.skip, skipbuf, skipbuf, FG_SKIP, FG_SKIP, tid);
+            part[tid] = fg_gemv<WT, 256, 3>(w.skip(), skipbuf, skipbuf, FG_SKIP, FG_SKIP, tid);
             __syncthreads();
             if (tid < 256) f1[tid] = tanhf(part[tid] + part[tid + 256] + part[tid + 512]);
             __syncthreads();
-            part[tid] = fg_gemv<WT, 256, 3>(w.skip_glu, f1, f1, 256, 256, tid);
+            part[tid] = fg_gemv<WT, 256, 3>(w.skip_glu(), f1, f1, 256, 256, tid);
             __syncthreads();
             if (tid < 256)
                 f1[tid] = f1[tid] * fg_sigmoid(
                     part[tid] + part[tid + 256] + part[tid + 512]);
             __syncthreads();
-            part[tid] = fg_gemv<WT, 64, 12>(w.out, f1, f1, 256, 256, tid);
+            part[tid] = fg_gemv<WT, 64, 12>(w.out(), f1, f1, 256, 256, tid);
             __syncthreads();
             if (tid < FG_SUB) {
                 float v = 0.f;
@@ -346,6 +397,9 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
 #define FG_G 8
 
 #define FG_UMAX 4              // utterances a cluster advances in lockstep
+#ifndef FG_INFLIGHT
+#define FG_INFLIGHT 4        // 16-byte weight loads per software-pipeline group
+#endif
 #define FG_SLOTS 416           // granules one member publishes per exchange (max 384 + 32)
 
 struct FgCluster {
@@ -536,32 +590,62 @@ __device__ __forceinline__ void fg_exchange_sum(
 // fields xa / xb of every FgLds); partial sums meet in LDS. sum[u] is valid
 // in threads tid < RW. Row split: RW = R / 8 rows of the full-K matrix;
 // K split: all RW = RPAD = R rows of this member's (R x K / 8) sub-matrix.
-template <class WT, int RW, int RPAD, int U>
+template <class WT, int RW, int RPAD, int U, int KPAD>
 __device__ __forceinline__ void fg_slice(
     const WT* __restrict__ w, const float* lds, int xa, int xb, int split,
-    int kpad, int r0, float* ldsw, int tid, float (&sum)[U]) {
+    int r0, float* ldsw, int tid, float (&sum)[U]) {
     constexpr int VEC = FgVec<WT>::VEC;
     constexpr int PARTS = FG_THREADS / RW;
+    constexpr int BLOCKS = KPAD / VEC;
+    constexpr int NB = (BLOCKS + PARTS - 1) / PARTS;   // blocks per thread
     const int row = tid % RW, p = tid / RW;
     float acc0[U], acc1[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc0[u] = acc1[u] = 0.f;
     if (p < PARTS) {
-        const int blocks = kpad / VEC;
-        const int b0 = p * blocks / PARTS, b1 = (p + 1) * blocks / PARTS;
+        const int b0 = p * BLOCKS / PARTS, b1 = (p + 1) * BLOCKS / PARTS;
         const int sb = split / VEC;
         const WT* wp = w + ((size_t)b0 * RPAD + r0 + row) * VEC;
-#pragma unroll 4
-        for (int b = b0; b < b1; ++b) {
-            float wf[VEC];
-            FgVec<WT>::unpack(*reinterpret_cast<const uint4*>(wp), wf);
-            const int off = b < sb ? xa + b * VEC : xb + (b - sb) * VEC;
+        // the stream is latency-bound (an L2 round trip per dependent batch
+        // of loads): software-pipelined in groups of FG_INFLIGHT 16-byte
+        // blocks - the next group is requested before the current one is
+        // used, so only the first round trip of a slice is exposed
+        constexpr int R = NB < FG_INFLIGHT ? NB : FG_INFLIGHT;
+        constexpr int NGROUP = (NB + R - 1) / R;
+        uint4 cur[R];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float d = FgVec<WT>::dotf(wf, lds + u * FG_LSTRIDE + off);
-                if (b & 1) acc1[u] += d; else acc0[u] += d;
+        for (int i = 0; i < R; ++i)
+            cur[i] = b0 + i < b1
+                ? *reinterpret_cast<const uint4*>(wp + (size_t)i * RPAD * VEC)
+                : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+        for (int gq = 0; gq < NGROUP; ++gq) {
+            const int first = b0 + gq * R;
+            uint4 nxt[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                nxt[i] = (gq + 1 < NGROUP && first + R + i < b1)
+                    ? *reinterpret_cast<const uint4*>(
+                          wp + (size_t)((gq + 1) * R + i) * RPAD * VEC)
+                    : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int b = first + i;
+                if (b < b1) {
+                    float wf[VEC];
+                    FgVec<WT>::unpack(cur[i], wf);
+                    const int off =
+                        b < sb ? xa + b * VEC : xb + (b - sb) * VEC;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float d =
+                            FgVec<WT>::dotf(wf, lds + u * FG_LSTRIDE + off);
+                        if (b & 1) acc1[u] += d; else acc0[u] += d;
+                    }
+                }
             }
-            wp += (size_t)RPAD * VEC;
+#pragma unroll
+            for (int i = 0; i < R; ++i) cur[i] = nxt[i];
         }
     }
 #pragma unroll
@@ -581,23 +665,25 @@ __device__ __forceinline__ void fg_slice(
     __syncthreads();
 }
 
-// K-split copies of the layers that contract a member-owned slice: member g's
-// (R x K / 8) sub-matrix W[:, g K / 8 : (g + 1) K / 8], packed like a matrix
-// of its own, the 8 of them back to back.
-template <class WT>
-struct FarganSplitWeights {
-    const WT* cond1;          // 8 x (384 x 48)
-    const WT* fwconv_glu;     // 8 x (256 x 32)
-    const WT* gru_glu[3];     // 8 x (256 x 32)
-    const WT* out;            // 8 x (64 x 32)
-};
-
 struct FarganClusterArgs {
     FarganArgs f;
     unsigned* state;      // per cluster: FG_CSTATE words of granules
     unsigned* error;
     int nclusters;
+#ifdef PM_TUNING
+    unsigned long long* timeline;   // debug: phase stamps of one sub-frame step
+#endif
 };
+
+#ifdef PM_TUNING
+#define FG_STAMP(i)                                                           \
+    do {                                                                      \
+        if (ca.timeline && blockIdx.x == 1 && tid == 0 && t == 7 && s == 1)   \
+            ca.timeline[i] = __builtin_amdgcn_s_memtime();                    \
+    } while (0)
+#else
+#define FG_STAMP(i) ((void)0)
+#endif
 
 // U utterances per cluster advance in lockstep: the weight slice is read once
 // per layer for all of them and one exchange carries U vectors, so the
@@ -605,7 +691,7 @@ struct FarganClusterArgs {
 // the batch <= 32 case (one utterance per cluster, 32 clusters = 256 CUs).
 template <class WT, int U>
 __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
-    FarganClusterArgs ca, FarganWeights<WT> w, FarganSplitWeights<WT> ws) {
+    FarganClusterArgs ca, FarganWeights<WT> w) {
     const FarganArgs& a = ca.f;
     constexpr int NT = FG_THREADS;
     constexpr int CPAD = 376;
@@ -629,12 +715,20 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
         // utterances u0 .. u0 + U - 1; slots past the batch replay the last
         // utterance (same arithmetic, stores masked) so every member of the
         // cluster runs the same number of exchanges
-        int ut[U];
+        int ut[U], len[U];
         bool live[U];
+        int frames = 0;          // the longest of the U utterances
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             live[u] = u0 + u < a.B;
             ut[u] = live[u] ? u0 + u : a.B - 1;
+            len[u] = a.lengths ? min(max(a.lengths[ut[u]], 0), T) : T;
+            frames = len[u] > frames ? len[u] : frames;
+            // zero the tail of a short utterance (each member its share)
+            if (live[u])
+                for (int i = len[u] * FG_HOP + g * NT + tid; i < T * FG_HOP;
+                     i += FG_G * NT)
+                    a.out[(size_t)ut[u] * T * FG_HOP + i] = 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -652,7 +746,14 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
         __syncthreads();
 
 #pragma unroll 1
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < frames; ++t) {
+            // Opaque copy of the thread id, renewed every frame / step: the
+            // per-thread weight addresses and K-slice bounds of the 13 matrix
+            // slices below are loop invariants, and hoisted out of this
+            // 3 444-step loop they occupy ~80 vector registers for the whole
+            // kernel (spills); recomputing them costs a few VALU per slice.
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
             int period[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -667,30 +768,32 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
             __syncthreads();
             float v[U], m[U], tot[U], ext[U];
             // ---- conditioning network (fargan.py:139-160): R, K, R ----
-            fg_slice<WT, 48, 384, U>(w.cond[0], lds, FG_OFF(condin), FG_OFF(condin),
-                                     CPAD, CPAD, g * 48, lds, tid, v);
+            fg_slice<WT, 48, 384, U, CPAD>(w.cond(0), lds, FG_OFF(condin),
+                                           FG_OFF(condin), CPAD, g * 48, lds,
+                                           tid, v);
             if (tid < 48) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) L[u].c1[g * 48 + tid] = tanhf(v[u]);
             }
             __syncthreads();
-            fg_slice<WT, 384, 384, U>(ws.cond1 + (size_t)g * (384 * 48), lds,
-                                      FG_OFF(c1) + g * 48, FG_OFF(c1) + g * 48,
-                                      48, 48, 0, lds, tid, v);
+            fg_slice<WT, 384, 384, U, 48>(w.k_cond1(g), lds,
+                                          FG_OFF(c1) + g * 48,
+                                          FG_OFF(c1) + g * 48, 48, 0, lds, tid, v);
             fg_exchange_sum<U, 384, 0>(c, v, v, lds, tid, tot, ext);
             if (tid < 384) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) L[u].c2[tid] = tanhf(tot[u]);
             }
             __syncthreads();
-            fg_slice<WT, 64, 512, U>(w.cond[2], lds, FG_OFF(c2), FG_OFF(c2), CPAD,
-                                     CPAD, g * 64, lds, tid, v);
+            fg_slice<WT, 64, 512, U, CPAD>(w.cond(2), lds, FG_OFF(c2), FG_OFF(c2),
+                                           CPAD, g * 64, lds, tid, v);
 #pragma unroll
             for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
             fg_exchange<U, 64>(c, m, lds, FG_OFF(cond), tid);
 
 #pragma unroll 1
             for (int s = 0; s < 4; ++s) {
+                asm volatile("" : "+v"(tid));
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     FgLds& S = L[u];
@@ -713,20 +816,25 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     }
                 }
                 __syncthreads();
+                FG_STAMP(0);
 
                 // ---- framewise conv (R) + its GLU gate (K): 1 exchange ----
-                fg_slice<WT, 32, 256, U>(w.fwconv, lds, FG_OFF(subin), FG_OFF(subin),
-                                         520, 520, g * 32, lds, tid, v);
+                fg_slice<WT, 32, 256, U, 520>(w.fwconv(), lds, FG_OFF(subin),
+                                              FG_OFF(subin), 520, g * 32, lds,
+                                              tid, v);
+                FG_STAMP(1);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     m[u] = tanhf(v[u]);
                     if (tid < 32) L[u].own[tid] = m[u];
                 }
                 __syncthreads();
-                fg_slice<WT, 256, 256, U>(ws.fwconv_glu + (size_t)g * (256 * 32),
-                                          lds, FG_OFF(own), FG_OFF(own), 32, 32, 0,
-                                          lds, tid, v);
+                fg_slice<WT, 256, 256, U, 32>(
+                    w.k_fwconv_glu(g), lds, FG_OFF(own),
+                    FG_OFF(own), 32, 0, lds, tid, v);
+                FG_STAMP(2);
                 fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                FG_STAMP(3);
                 if (tid < 256) {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
@@ -742,11 +850,12 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     const int hoff = FG_OFF(hid) + n * FG_HOP;
                     // this member's 32 units x 3 gates = packed rows g*96 ..
                     float gi[U], gh[U];
-                    fg_slice<WT, 96, 768, U>(w.gru_ih[n], lds, xa,
-                                             FG_OFF(skipbuf) + 1024, 256, 384,
-                                             g * 96, lds, tid, gi);
-                    fg_slice<WT, 96, 768, U>(w.gru_hh[n], lds, hoff, hoff, 256, 256,
-                                             g * 96, lds, tid, gh);
+                    fg_slice<WT, 96, 768, U, 384>(w.gru_ih(n), lds, xa,
+                                                  FG_OFF(skipbuf) + 1024, 256,
+                                                  g * 96, lds, tid, gi);
+                    fg_slice<WT, 96, 768, U, 256>(w.gru_hh(n), lds, hoff, hoff, 256,
+                                                  g * 96, lds, tid, gh);
+                    FG_STAMP(4 + 4 * n);
                     if (tid < 96) {
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
@@ -769,10 +878,13 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                         m[u] = hnew;
                     }
                     __syncthreads();
-                    fg_slice<WT, 256, 256, U>(
-                        ws.gru_glu[n] + (size_t)g * (256 * 32), lds, FG_OFF(own),
-                        FG_OFF(own), 32, 32, 0, lds, tid, v);
+                    FG_STAMP(5 + 4 * n);
+                    fg_slice<WT, 256, 256, U, 32>(
+                        w.k_gru_glu(n, g), lds, FG_OFF(own),
+                        FG_OFF(own), 32, 0, lds, tid, v);
+                    FG_STAMP(6 + 4 * n);
                     fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                    FG_STAMP(7 + 4 * n);
                     if (tid < 256) {
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
@@ -785,30 +897,37 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
 
                 // ---- skip dense (R): vector exchange ----
-                fg_slice<WT, 32, 256, U>(w.skip, lds, FG_OFF(skipbuf), FG_OFF(skipbuf),
-                                         FG_SKIP, FG_SKIP, g * 32, lds, tid, v);
+                FG_STAMP(16);
+                fg_slice<WT, 32, 256, U, FG_SKIP>(w.skip(), lds, FG_OFF(skipbuf),
+                                                  FG_OFF(skipbuf), FG_SKIP, g * 32,
+                                                  lds, tid, v);
+                FG_STAMP(17);
 #pragma unroll
                 for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
                 fg_exchange<U, 32>(c, m, lds, FG_OFF(f1), tid);
+                FG_STAMP(18);
                 // ---- skip GLU (R) + output layer (K): 1 exchange ----
-                fg_slice<WT, 32, 256, U>(w.skip_glu, lds, FG_OFF(f1), FG_OFF(f1), 256,
-                                         256, g * 32, lds, tid, v);
+                fg_slice<WT, 32, 256, U, 256>(w.skip_glu(), lds, FG_OFF(f1), FG_OFF(f1),
+                                              256, g * 32, lds, tid, v);
                 if (tid < 32) {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
                         L[u].own[tid] = L[u].f1[g * 32 + tid] * fg_sigmoid(v[u]);
                 }
                 __syncthreads();
-                fg_slice<WT, 64, 64, U>(ws.out + (size_t)g * (64 * 32), lds,
-                                        FG_OFF(own), FG_OFF(own), 32, 32, 0, lds,
-                                        tid, v);
+                FG_STAMP(19);
+                fg_slice<WT, 64, 64, U, 32>(w.k_out(g), lds,
+                                            FG_OFF(own), FG_OFF(own), 32, 0, lds,
+                                            tid, v);
+                FG_STAMP(20);
                 fg_exchange_sum<U, 64, 0>(c, v, v, lds, tid, tot, ext);
+                FG_STAMP(21);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     FgLds& S = L[u];
                     if (tid < FG_SUB) {
                         const float sample = tanhf(tot[u]);
-                        if (tid / 8 == g && live[u])
+                        if (tid / 8 == g && live[u] && t < len[u])
                             a.out[((size_t)ut[u] * T + t) * FG_HOP + s * FG_SUB +
                                   tid] = sample;
                         S.prev[(base + tid) & (FG_PREV - 1)] = sample;
@@ -818,6 +937,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 base = (base + FG_SUB) & (FG_PREV - 1);
                 __syncthreads();
+                FG_STAMP(22);
             }
         }
     }

@@ -574,3 +574,63 @@ __global__ __launch_bounds__(256) void pm_grid_sample_kernel(
     y = y * scale + offset;
     out[(size_t)r * n_out + j] = fminf(fmaxf(y, lo), hi);
 }
+
+// ---------------------------------------------------------------------------
+// promonet.edit.from_features with stretch_unvoiced / stretch_silence off
+// (edit/core.py:57-110): a time-stretch grid whose step size follows the
+// probability mass of the SELECTED phonemes, so that only those are stretched.
+//   selected[t] = sum_k ppg[indices[k]][t]
+//   effective   = (target - (T - sum selected)) / sum selected
+//   grid[j]     = grid[j - 1] + 1 / (p effective + 1 - p),  p = selected
+//                 interpolated at grid[j - 1]
+// Phase 1 is parallel; phase 2 is the reference's sequential fp32 recurrence
+// (each step depends on the previous position), walked by one thread out of
+// LDS - a few hundred dependent steps, microseconds.
+// ---------------------------------------------------------------------------
+struct StretchArgs {
+    const float* ppg;      // (P, T)
+    const int* indices;    // (n) selected phoneme rows
+    float* selected;       // (T) scratch, also returned for inspection
+    float* grid;           // (target)
+    int n, T, target;
+};
+
+__global__ __launch_bounds__(256) void pm_stretch_grid_kernel(StretchArgs a) {
+    extern __shared__ float sel_lds[];         // T floats when they fit
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const bool in_lds = (size_t)a.T * sizeof(float) <= 64 * 1024;
+    float partial = 0.f;
+    for (int t = tid; t < a.T; t += 256) {
+        float s = 0.f;
+        for (int k = 0; k < a.n; ++k) s += a.ppg[(size_t)a.indices[k] * a.T + t];
+        a.selected[t] = s;
+        if (in_lds) sel_lds[t] = s;
+        partial += s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = partial;
+    __syncthreads();
+    if (tid != 0) return;
+    const float* sel = in_lds ? sel_lds : a.selected;
+    const float total = red[0] + red[1] + red[2] + red[3];
+    const float unselected = (float)a.T - total;
+    const float effective = ((float)a.target - unselected) / total;
+    float position = 0.f;
+    a.grid[0] = 0.f;
+    for (int j = 1; j < a.target; ++j) {
+        int left = (int)floorf(position);
+        left = left < a.T - 1 ? left : a.T - 1;
+        float probability;
+        if (left + 1 < a.T) {
+            const float offset = position - (float)left;
+            probability = offset * sel[left + 1] + (1.f - offset) * sel[left];
+        } else {
+            probability = sel[left];
+        }
+        const float ratio = probability * effective + (1.f - probability);
+        position += 1.f / ratio;
+        a.grid[j] = position;
+    }
+}

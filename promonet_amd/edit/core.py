@@ -24,33 +24,29 @@ def from_features(
     stretch_silence: bool = True,
     return_grid: bool = False
 ):
-    """Edit speech representation (edit/core.py:17-132)
+    """Apply pitch-shift / time-stretch / loudness edits to one utterance's
+    features on the GPU. Same signature and return convention as the
+    reference (edit/core.py:17-132).
 
-    Arguments
-        loudness: Loudness contour to edit
-        pitch: Pitch contour to edit
-        periodicity: Periodicity contour to edit
-        ppg: PPG to edit
-        pitch_shift_cents: Amount of pitch-shifting in cents
-        time_stretch_ratio: Amount of time-stretching. Faster when above one.
-        loudness_scale_db: Loudness ratio editing in dB
-        stretch_unvoiced: If true, applies time-stretching to unvoiced frames
-        stretch_silence: If true, applies time-stretching to silent frames
-        return_grid: If true, also returns the time-stretch grid
-
-    Returns
-        edited_loudness, edited_pitch, edited_periodicity, edited_ppg
+    loudness (bands, T) dB, pitch (1, T) Hz, periodicity (1, T) and ppg
+    (40, T) come back edited, in that order (plus the stretch grid when
+    `return_grid`). `pitch_shift_cents` multiplies the pitch by 2^(cents /
+    1200) and clips it to [FMIN, FMAX]; `time_stretch_ratio` > 1 shortens the
+    utterance (all four features are resampled on one grid, the pitch in the
+    log2 domain); `loudness_scale_db` is added to the loudness.
+    `stretch_unvoiced=False` / `stretch_silence=False` leave unvoiced /
+    silent frames at their original speed: the grid then steps by the
+    probability mass of the remaining phonemes (edit/core.py:57-110).
+    Inputs are never modified (the reference's `loudness +=` is in place).
     """
-    if not (stretch_unvoiced and stretch_silence) and \
-            time_stretch_ratio is not None:
-        raise NotImplementedError(
-            'voiced-only time-stretching walks the phoneme inventory of the '
-            'third-party `ppgs` package on the host (edit/core.py:57-110): '
-            'out of scope')
-
     grid = None
     if time_stretch_ratio is not None:
-        grid = _grid.constant(ppg, time_stretch_ratio)
+        if stretch_unvoiced and stretch_silence:
+            grid = _grid.constant(ppg, time_stretch_ratio)
+        else:
+            grid = _grid.selective(
+                ppg, time_stretch_ratio,
+                stretched_phonemes(stretch_unvoiced, stretch_silence))
     ratio = 1. if pitch_shift_cents is None else \
         promonet_amd.convert.cents_to_ratio(pitch_shift_cents)
     offset = 0. if loudness_scale_db is None else float(loudness_scale_db)
@@ -72,6 +68,22 @@ def from_features(
     if return_grid:
         return loudness, pitch, periodicity, ppg, grid
     return loudness, pitch, periodicity, ppg
+
+
+def stretched_phonemes(stretch_unvoiced, stretch_silence):
+    """Rows of the PPG whose probability mass is time-stretched
+    (edit/core.py:57-76): the voiced phonemes, plus silence and / or the
+    unvoiced rest on request. The inventory is the third-party ppgs / pypar
+    one, restated in promonet_amd.config (PHONEMES, VOICED, SILENCE)."""
+    index = {p: i for i, p in enumerate(promonet_amd.PHONEMES)}
+    indices = [index[p] for p in promonet_amd.VOICED]
+    if stretch_silence:
+        indices.append(index[promonet_amd.SILENCE])
+    if stretch_unvoiced:
+        indices.extend(
+            index[p] for p in promonet_amd.PHONEMES
+            if p not in promonet_amd.VOICED and p != promonet_amd.SILENCE)
+    return indices
 
 
 def from_file(

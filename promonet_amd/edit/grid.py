@@ -54,3 +54,24 @@ def constant(tensor, ratio):
     """Grid for constant-ratio time-stretching (> 1 is faster).
     `ppgs.edit.grid.constant` restated (PARITY UNPINNED)."""
     return of_length(tensor, round(tensor.shape[-1] / ratio + 1e-4))
+
+
+def selective(ppg, ratio, indices):
+    """Grid that time-stretches only where the phonemes `indices` (rows of
+    `ppg` (P, frames)) carry the probability mass (edit/core.py:77-110): the
+    reference's sequential recurrence, run on the device
+    (`pm_stretch_grid`)."""
+    _lib.require_gpu(ppg)
+    lib = _lib.lib()
+    ppg = ppg.to(torch.float32).contiguous()
+    frames = ppg.shape[-1]
+    target = round(frames / ratio)
+    rows = torch.tensor(list(indices), dtype=torch.int32, device=ppg.device)
+    selected = torch.empty(frames, device=ppg.device)
+    grid = torch.empty(target, device=ppg.device)
+    with torch.cuda.device(ppg.device):
+        _lib.check(lib.pm_stretch_grid(
+            _lib.ptr(ppg), _lib.ptr(rows, torch.int32), rows.numel(),
+            _lib.ptr(selected), _lib.ptr(grid), frames, target,
+            _lib.stream()))
+    return grid

@@ -138,11 +138,14 @@ class FARGAN(torch.nn.Module):
         return self._run(features, global_features, previous_samples, False)
 
     def forward_channels_last(
-        self, features_cl, global_features, previous_samples
+        self, features_cl, global_features, previous_samples, lengths=None
     ):
-        return self._run(features_cl, global_features, previous_samples, True)
+        """`lengths` (B,) frames: ragged batch of zero-padded utterances, each
+        synthesised exactly as if alone (the model is causal); tails are 0."""
+        return self._run(
+            features_cl, global_features, previous_samples, True, lengths)
 
-    def _run(self, x, g, previous, channels_last):
+    def _run(self, x, g, previous, channels_last, lengths=None):
         _lib.require_gpu(x)
         engine = self.engine()
         lib = _lib.lib()
@@ -174,13 +177,27 @@ class FARGAN(torch.nn.Module):
                 self._workspace = torch.empty(
                     size, dtype=torch.uint8, device=x.device)
 
+            if lengths is not None:
+                lengths = torch.as_tensor(lengths).to(
+                    device=x.device, dtype=torch.int32).contiguous()
+                if lengths.shape != (batch,):
+                    raise ValueError('lengths must have shape (B,)')
+
             def launch():
                 _lib.check(lib.pm_fargan_set_mode(engine, self.kernel_mode))
-                _lib.check(lib.pm_fargan_forward(
-                    engine, _lib.ptr(x), int(channels_last), _lib.ptr(g),
-                    g.shape[0], pointer, pbatch, _lib.ptr(out), batch, frames,
-                    self._workspace.data_ptr(), self._workspace.numel(),
-                    _lib.stream()))
+                if lengths is None:
+                    _lib.check(lib.pm_fargan_forward(
+                        engine, _lib.ptr(x), int(channels_last), _lib.ptr(g),
+                        g.shape[0], pointer, pbatch, _lib.ptr(out), batch,
+                        frames, self._workspace.data_ptr(),
+                        self._workspace.numel(), _lib.stream()))
+                else:
+                    _lib.check(lib.pm_fargan_forward_ragged(
+                        engine, _lib.ptr(x), int(channels_last), _lib.ptr(g),
+                        g.shape[0], pointer, pbatch,
+                        _lib.ptr(lengths, torch.int32), _lib.ptr(out), batch,
+                        frames, self._workspace.data_ptr(),
+                        self._workspace.numel(), _lib.stream()))
                 if self.check_exchange:
                     # the cluster kernel's inter-workgroup waits are bounded;
                     # a tripped bound must not pass as audio (one stream sync)

@@ -93,10 +93,8 @@ class Generator(torch.nn.Module):
         if self.fargan:
             if previous_samples is None:
                 previous_samples = self.default_previous_samples
-            if lengths is not None:
-                raise NotImplementedError('ragged FARGAN batches')
             return self.model.forward_channels_last(
-                features_cl, global_features, previous_samples)
+                features_cl, global_features, previous_samples, lengths)
         return self.model.forward_channels_last(
             features_cl, global_features, lengths)
 

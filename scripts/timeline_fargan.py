@@ -1,0 +1,39 @@
+"""Phase timeline of one sub-frame step of the FARGAN cluster kernel (debug
+tool for a -DPM_TUNING build, GPU box): s_memtime stamps (100 MHz) of member 1
+of cluster 0 at frame 7, sub-frame 1."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import promonet_amd  # noqa: E402
+from promonet_amd import _lib  # noqa: E402
+from bench import synthetic_inputs  # noqa: E402
+
+device = torch.device('cuda:0')
+promonet_amd.configure(MODEL='fargan')
+torch.manual_seed(0)
+model = promonet_amd.model.Generator().to(device).eval()
+lib = _lib.lib()
+for batch in (32, 64):
+    inputs = synthetic_inputs(batch, 40, 1234, device)
+    stamps = torch.zeros(64, dtype=torch.int64, device=device)
+    with torch.inference_mode():
+        model(*inputs, None)
+        torch.cuda.synchronize()
+        _lib.check(lib.pm_debug_timeline(stamps.data_ptr()))
+        model(*inputs, None)
+        torch.cuda.synchronize()
+        lib.pm_debug_timeline(None)
+    t = stamps.cpu().tolist()
+    names = {1: 'fwconv rows', 2: 'fwconv_glu cols', 3: 'exchange sum'}
+    for n in range(3):
+        names.update({4 + 4 * n: f'gru{n} ih+hh rows', 5 + 4 * n: f'gru{n} cell',
+                      6 + 4 * n: f'glu{n} cols', 7 + 4 * n: f'exchange sum'})
+    names.update({16: '-', 17: 'skip rows', 18: 'exchange vec',
+                  19: 'skip_glu rows', 20: 'out cols', 21: 'exchange sum',
+                  22: 'state update'})
+    print(f'batch {batch}: step total {(t[22] - t[0]) * 10} ns')
+    for i in range(1, 23):
+        print(f'  {names[i]:18s} {(t[i] - t[i - 1]) * 10:6d} ns')

@@ -224,3 +224,83 @@ def test_sparsify_second_source():
     masked = torch.where(ppg > .05, ppg, torch.zeros_like(ppg)) + 1e-8
     assert torch.allclose(
         constant, masked / masked.sum(-2, keepdim=True), rtol=1e-4, atol=1e-12)
+
+
+def test_selective_time_stretch():
+    """edit/core.py:57-110 restated vs the golden of the real reference."""
+    from conftest import GOLDEN
+    entry = torch.load(GOLDEN / 'edit_voiced.pt', weights_only=False)
+    inputs = oracle.synthetic_inputs(1, entry['frames'], seed=entry['input_seed'])
+    for case in entry['cases']:
+        out = oracle.edit_from_features(
+            inputs[0][0], inputs[1], inputs[2], inputs[3][0],
+            case['pitch_shift_cents'], case['time_stretch_ratio'], None, None,
+            case['stretch_unvoiced'], case['stretch_silence'])
+        grid = oracle.grid_selective(
+            inputs[3][0], case['time_stretch_ratio'],
+            oracle.stretched_phonemes(
+                case['stretch_unvoiced'], case['stretch_silence']))
+        assert max_abs(grid, case['grid']) < 1e-5
+        for mine, want in zip(out, case['outputs']):
+            assert mine.shape == want.shape and max_abs(mine, want) < 1e-3
+    # a stretched-everything selection degenerates to a constant step
+    grid = oracle.grid_selective(inputs[3][0], 2., list(range(40)))
+    assert grid.shape == (30,)
+    assert torch.allclose(
+        grid[1:] - grid[:-1], torch.full((29,), 61. / 30.), atol=1e-3)
+
+
+def test_a_weighting_second_source():
+    """librosa.A_weighting is unpinned (package absent): second-source the
+    restated closed form against the ANALOG A-weighting filter of IEC 61672
+    evaluated with scipy.signal.freqs (poles at 20.6 Hz x2, 107.7 Hz, 737.9 Hz,
+    12194 Hz x2, four zeros at DC, 0 dB at 1 kHz)."""
+    import numpy as np
+    import scipy.signal
+    f1, f2, f3, f4 = 20.598997, 107.65265, 737.86223, 12194.217
+    poles = -2 * np.pi * np.array([f1, f1, f2, f3, f4, f4])
+    b, a = scipy.signal.zpk2tf([0., 0., 0., 0.], poles, 1.)
+    freqs = np.linspace(0, 11025, 513)[1:]                 # skip DC (-inf)
+    _, h = scipy.signal.freqs(b, a, 2 * np.pi * freqs)
+    _, h1k = scipy.signal.freqs(b, a, [2 * np.pi * 1000.])
+    analog = 20 * np.log10(np.abs(h) / np.abs(h1k))
+    restated = oracle.a_weighting(freqs, min_db=-1e9)
+    # the closed form's "+ 2.0" is the 1 kHz normalisation rounded to 0.01 dB
+    assert np.abs(restated - analog).max() < 5e-3
+    full = oracle.a_weighting(np.linspace(0, 11025, 513))
+    assert full[0] == -80. and abs(full[46] - 0.) < .05     # DC floor; ~991 Hz
+    # the IEC 61672 table
+    for hz, db in ((100., -19.1), (1000., 0.), (10000., -2.5), (31.5, -39.4)):
+        assert abs(oracle.a_weighting(np.array([hz]))[0] - db) < .2   # nominal band centres
+    weights = oracle.perceptual_weights()
+    assert weights.shape == (513, 1) and weights[0, 0] == -100.
+
+
+def test_mel_basis_second_source():
+    """librosa.filters.mel is unpinned: check the restated basis against the
+    Slaney Auditory-Toolbox definition it implements - linear below 1 kHz at
+    200/3 Hz per mel, log-spaced above with 27 steps per factor 6.4, unit-area
+    triangles (slaney norm) - and against the product's copy."""
+    import numpy as np
+    assert abs(float(oracle.hz_to_mel_slaney(torch.tensor(1000.))) - 15.) < 1e-6
+    assert abs(float(oracle.hz_to_mel_slaney(torch.tensor(6400.))) - 42.) < 1e-5
+    assert abs(float(oracle.mel_to_hz_slaney(torch.tensor(3.))) - 200.) < 1e-4
+    round_trip = oracle.mel_to_hz_slaney(
+        oracle.hz_to_mel_slaney(torch.tensor([50., 999., 1001., 8000.])))
+    assert torch.allclose(
+        torch.as_tensor(round_trip).float(),
+        torch.tensor([50., 999., 1001., 8000.]), rtol=1e-6)
+    basis = oracle.mel_basis().double().numpy()
+    assert basis.shape == (80, 513) and (basis >= 0).all()
+    assert (basis.sum(1) > 0).all()                      # no empty filter
+    # slaney norm: every triangle has unit area in Hz (sampled every 21.5 Hz;
+    # the narrow low filters are sampled coarsely)
+    area = basis.sum(1) * (11025. / 512)
+    assert np.abs(area[30:] - 1.).max() < .05
+    assert np.abs(area - 1.).max() < .35
+    # peaks ascend, one filter's peak is the next one's lower edge
+    peaks = basis.argmax(1)
+    assert (np.diff(peaks) >= 0).all() and peaks[0] >= 1 and peaks[-1] < 512
+    import promonet_amd
+    ours = promonet_amd.preprocess.spectrogram.mel_basis()
+    assert max_abs(ours, oracle.mel_basis()) < 1e-7

@@ -43,9 +43,40 @@ def test_from_features_golden(device, golden_default):
             assert max_abs(mine, want) < tolerance, case
     # inputs are never mutated (the reference's `loudness +=` is in place)
     assert torch.equal(loud.cpu(), inputs[0][0])
-    with pytest.raises(NotImplementedError):
-        promonet_amd.edit.from_features(
-            loud, pit, per, pg, time_stretch_ratio=1.2, stretch_unvoiced=False)
+
+
+def test_selective_time_stretch_golden(device):
+    """stretch_unvoiced / stretch_silence off (edit/core.py:57-110): the grid
+    is a sequential fp32 recurrence over the selected phonemes' probability;
+    golden from the REAL reference loop (phoneme inventory restated)."""
+    import promonet_amd
+    from conftest import GOLDEN
+    entry = torch.load(GOLDEN / 'edit_voiced.pt', weights_only=False)
+    inputs = oracle.synthetic_inputs(1, entry['frames'], seed=entry['input_seed'])
+    loud, pit, per, pg = (
+        inputs[0][0].to(device), inputs[1].to(device), inputs[2].to(device),
+        inputs[3][0].to(device))
+    for case in entry['cases']:
+        got = promonet_amd.edit.from_features(
+            loud, pit, per, pg, case['pitch_shift_cents'],
+            case['time_stretch_ratio'], None, case['stretch_unvoiced'],
+            case['stretch_silence'], return_grid=True)
+        assert got[4].shape == case['grid'].shape
+        error = max_abs(got[4], case['grid'])
+        print(f"selective stretch {case['time_stretch_ratio']}: grid {error:.3e}")
+        assert error < 1e-3          # frames; 60 dependent fp32 steps
+        for mine, want, tolerance in zip(
+                got[:4], case['outputs'], (2e-2, 2e-1, 1e-3, 1e-3)):
+            assert mine.shape == want.shape
+            assert max_abs(mine, want) < tolerance, case
+    # the combination the reference cannot run (it mixes phoneme strings into
+    # its index list): every phoneme but silence is stretched
+    got = promonet_amd.edit.from_features(
+        loud, pit, per, pg, time_stretch_ratio=1.2, stretch_unvoiced=True,
+        stretch_silence=False, return_grid=True)
+    want = oracle.grid_selective(
+        inputs[3][0], 1.2, oracle.stretched_phonemes(True, False))
+    assert max_abs(got[4], want) < 1e-3
 
 
 def test_edit_then_synthesize_stays_on_device(device, golden_default):

@@ -150,3 +150,29 @@ def test_deterministic_and_batch_independent(device, fargan_model):
         single = model(*[t[3:4] for t in inputs], None)
     assert torch.equal(full, again)
     assert torch.equal(single[0], full[3])
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_ragged_batch_is_exact(device, fargan_model, mode):
+    """Zero-padded utterances of different lengths in one batch (more of them
+    than clusters, so several advance in lockstep): the model is causal, each
+    equals its stand-alone synthesis bit for bit, the tails are zero."""
+    model = fargan_model('fp32')
+    lengths = [9, 1, 14, 5, 14, 3] * 6 + [7]          # 37 utterances
+    frames = max(lengths)
+    inputs = on(device, oracle.synthetic_inputs(len(lengths), frames, seed=33))
+    for item, length in enumerate(lengths):           # garbage past the end
+        for tensor in inputs[:4]:
+            tensor[item, ..., length:] = 7.
+    model.model.kernel_mode = mode
+    with torch.inference_mode():
+        ragged = model(*inputs, None, lengths=lengths)
+        for item in (0, 1, 2, 5, 36):
+            length = lengths[item]
+            single = model(
+                *[t[item:item + 1, ..., :length] if t.ndim >= 2
+                  else t[item:item + 1] for t in inputs], None)
+            assert torch.equal(ragged[item, :, :length * 256], single[0]), item
+            if length < frames:
+                assert ragged[item, :, length * 256:].abs().max().item() == 0.
+    model.model.kernel_mode = 0
