@@ -200,6 +200,28 @@ int pm_block_cl(int dtype, const float* x_cl, float* out_cl,
                 const int* dilations, int niter, int batch, int length,
                 int channels, int kernel_size, int mode, float scale,
                 void* workspace, size_t workspace_bytes, void* stream);
+/* The whole MRF ResidualBlock of one stage (hifigan.py:141-145):
+ * out = (Block_3(x) + Block_7(x) + Block_11(x)) / 3 in one launch, the sum
+ * held in registers (32 channels). w1/b1/w2/b2: HOST arrays of 3 * niter
+ * device pointers, Block-major (k = 3 first);
+ * workspace >= 3 * niter * pm_op_workspace_bytes(c, c, 11)                  */
+int pm_mrf_cl(int dtype, const float* x_cl, float* out_cl,
+              const float* const* w1, const float* const* b1,
+              const float* const* w2, const float* const* b2,
+              const int* dilations, int niter, int batch, int length,
+              int channels, void* workspace, size_t workspace_bytes,
+              void* stream);
+/* Input layers (hifigan.py:19-30, 67-68): Conv1d(c_in, c_out, 7, padding 3)
+ * of the channels-last features + the k = 1 speaker conv of the (B|1, G)
+ * global features as a per-utterance bias. workspace >=
+ * pm_op_workspace_bytes(c_in, c_out, 7) + 256-aligned batch * pad32(c_out) * 4 */
+int pm_input_conv_cl(int dtype, const float* x_cl, float* out_cl,
+                     const float* weight, const float* bias,
+                     const float* global_features,
+                     const float* speaker_weight, const float* speaker_bias,
+                     int global_batch, int global_channels, int batch,
+                     int length, int c_in, int c_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* lrelu(optional) -> ConvTranspose1d(c_in, c_out, k = 2 r, stride r,
  * padding r / 2) (hifigan.py:97-106), channels-last: (B, L, c_in_pad) ->
  * (B, L * r, c_out_pad)                                                   */

@@ -1077,6 +1077,103 @@ extern "C" int pm_block_cl(
     return PM_OK;
 }
 
+// Whole MRF ResidualBlock (hifigan.py:141-145): out = (B_3(x) + B_7(x) +
+// B_11(x)) / 3, the three Blocks k = 3, 7, 11 (niter dilations each) in ONE
+// launch with their sum held in registers. Only where the whole-MRF kernel
+// exists (32 channels); w1 / b1 / w2 / b2 are HOST arrays of 3 * niter device
+// pointers, Block-major. workspace >= 3 * niter * pm_op_workspace_bytes(c, c, 11).
+extern "C" int pm_mrf_cl(
+    int dtype, const float* x, float* out, const float* const* w1,
+    const float* const* b1, const float* const* w2, const float* const* b2,
+    const int* dilations, int niter, int B, int L, int C, void* ws,
+    size_t ws_bytes, void* stream) {
+    if (!x || !out || !w1 || !b1 || !w2 || !b2 || !dilations || !ws)
+        return fail(PM_EINVAL, "null argument");
+    const int Cp = pad32(C);
+    if (Cp != 32)
+        return fail(PM_EINVAL, "whole-MRF kernel exists for <= 32 channels");
+    if (niter < 1 || niter > 3) return fail(PM_EINVAL, "1..3 dilations");
+    const size_t per = pm_op_workspace_bytes(C, C, 11);
+    if (ws_bytes < 3 * (size_t)niter * per)
+        return fail(PM_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    static const int KS[3] = {3, 7, 11};
+    Block3Args blocks[3] = {};
+    for (int j = 0; j < 3; ++j) {
+        ConvGeom g;
+        g.mode = 0; g.cout = g.cin = C; g.k = KS[j];
+        g.cout_pad = g.cin_pad = g.M = Cp; g.kt = KS[j]; g.ch = Cp;
+        g.bias_step = true;
+        Block3Args& a = blocks[j];
+        a.x = x; a.out = out; a.niter = niter; a.B = B; a.L = L;
+        a.mode = j == 0 ? 1 : 2; a.scale = 1.f / 3.f;
+        const size_t wsz = align256(((size_t)Cp * Cp * KS[j] + Cp * 16) * 4);
+        for (int n = 0; n < niter; ++n) {
+            char* base = (char*)ws + (size_t)(j * niter + n) * per;
+            void* p1 = base; void* p2 = base + wsz;
+            float* pb1 = (float*)(base + 2 * wsz);
+            float* pb2 = pb1 + align256(Cp * 64 * 4) / 4;
+            const int i = j * niter + n;
+            HIP_TRY(pack_weights(dtype, g, w1[i], p1, s));
+            HIP_TRY(pack_weights(dtype, g, w2[i], p2, s));
+            HIP_TRY(pad_bias(b1[i], pb1, C, Cp, 1, s));
+            HIP_TRY(pad_bias(b2[i], pb2, C, Cp, 1, s));
+            HIP_TRY(pack_bias_step(dtype, g, pb1, p1, s));
+            HIP_TRY(pack_bias_step(dtype, g, pb2, p2, s));
+            a.w1[n] = p1; a.w2[n] = p2; a.dil[n] = dilations[n];
+        }
+    }
+    hipError_t e = launch_mrf(dtype, Cp, blocks, s);
+    if (e == hipErrorNotSupported)
+        return fail(PM_EINVAL, "no whole-MRF kernel for this shape");
+    HIP_TRY(e);
+    return PM_OK;
+}
+
+// Input layers (hifigan.py:19-30, 67-68): Conv1d(c_in -> c_out, k 7, pad 3) on
+// channels-last features plus the speaker conditioning Conv1d(G -> c_out, k 1)
+// of the (B|1, G) global features, added as a per-utterance bias.
+//   x_cl (B, L, pad32(c_in)), w (c_out, c_in, 7), bias (c_out),
+//   global (gbatch, G), ws_w (c_out, G), ws_b (c_out)  ->  (B, L, pad32(c_out))
+extern "C" int pm_input_conv_cl(
+    int dtype, const float* x, float* out, const float* w, const float* bias,
+    const float* global, const float* ws_w, const float* ws_b, int gbatch,
+    int G, int B, int L, int c_in, int c_out, void* ws, size_t ws_bytes,
+    void* stream) {
+    if (!x || !out || !w || !bias || !global || !ws_w || !ws_b || !ws)
+        return fail(PM_EINVAL, "null argument");
+    if (gbatch != 1 && gbatch != B)
+        return fail(PM_EINVAL, "global batch must be 1 or batch");
+    const int cip = pad32(c_in), cop = pad32(c_out);
+    if (cop % 64 && cop != 32)
+        return fail(PM_EINVAL, "output channels %d unsupported", c_out);
+    if (ws_bytes < pm_op_workspace_bytes(c_in, c_out, 7) +
+                       align256((size_t)B * cop * 4))
+        return fail(PM_ENOMEM, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ConvGeom g;
+    g.mode = 0; g.cout = c_out; g.cin = c_in; g.k = 7;
+    g.cout_pad = g.M = cop; g.cin_pad = cip; g.kt = 7;
+    g.ch = (cip % 64 == 0) ? 64 : 32;
+    const int cfg = single_cfg(g.M, g.ch, 1);
+    char* base = (char*)ws;
+    const size_t wsz = 2 * align256(((size_t)cip * cop * 7 + cop * 16) * 4);
+    float* pb = (float*)(base + wsz);
+    float* gbias = (float*)(base + pm_op_workspace_bytes(c_in, c_out, 7));
+    HIP_TRY(pack_weights(dtype, g, w, base, s));
+    HIP_TRY(pad_bias(bias, pb, c_out, cop, 1, s));
+    hipLaunchKernelGGL(pm_speaker_bias_kernel, dim3((cop + 3) / 4, gbatch),
+                       dim3(256), 0, s, global, ws_w, ws_b, gbias, G, c_out,
+                       cop);
+    HIP_TRY(hipGetLastError());
+    SingleArgs a = {};
+    a.x = x; a.out = out; a.w = base; a.bias = pb; a.gbias = gbias;
+    a.gbias_batch = gbatch; a.B = B; a.L = L; a.Lout = L; a.Cin = cip;
+    a.M = cop; a.lrelu = 0; a.pad = 3; a.phase_r = 0; a.phase_c = 1;
+    HIP_TRY(launch_single(dtype, 0, g.ch, cfg, a, s));
+    return PM_OK;
+}
+
 extern "C" int pm_conv_transpose_cl(
     int dtype, const float* x, float* out, const float* w, const float* bias,
     int B, int L, int c_in, int c_out, int r, int lrelu, void* ws,
@@ -1494,13 +1591,7 @@ extern "C" int pm_fargan_create(
         delete h;
         return fail(PM_ESTATE, "FARGAN layer table and FarganWeights disagree");
     }
-    const size_t esize = weight_dtype == PM_F32 ? 4 : 2;
-    hipError_t e = hipMalloc(&h->weights, W::TOTAL * esize);
-    if (e != hipSuccess) {
-        delete h;
-        return fail(PM_EHIP, "hipMalloc: %s", hipGetErrorString(e));
-    }
-    *out = h;
+    *out = h;      // the weight buffer is allocated with the first tensor
     return PM_OK;
 }
 
@@ -1538,6 +1629,9 @@ static hipError_t fargan_pack_t(
 }
 
 static int fargan_pack(pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) {
+    if (!h->weights)
+        HIP_TRY(hipMalloc(&h->weights, FarganWeights<float>::TOTAL *
+                                           (h->dtype == PM_F32 ? 4 : 2)));
     if (h->dtype == PM_F32) HIP_TRY(fargan_pack_t<float>(h, l, w, s));
     else HIP_TRY(fargan_pack_t<_Float16>(h, l, w, s));
     l.has = true;

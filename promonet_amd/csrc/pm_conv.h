@@ -264,18 +264,9 @@ __host__ __device__ constexpr int pair_smem_bytes(int d) {
     return ALIAS ? (x > inter ? x : inter) : x + inter;
 }
 
-// 4-wave workgroups may be asked to leave room for a second one on the CU
-// (2 waves per SIMD -> at most 256 registers)
-#ifndef PM_PAIR_MINWAVES4
-#define PM_PAIR_MINWAVES4 1
-#endif
-#ifndef PM_BLOCK_MINWAVES4
-#define PM_BLOCK_MINWAVES4 2
-#endif
 template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS>
-__global__ __launch_bounds__(WM * WN * 64,
-                             WM * WN == 4 && ET::ESZ == 2 ? PM_PAIR_MINWAVES4 : 1)
-void conv_pair_kernel(PairArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
+    PairArgs a) {
     typedef typename ET::frag_t frag_t;
     constexpr int NCH = C / CH;
     constexpr int KC = CH / 16;
@@ -289,7 +280,11 @@ void conv_pair_kernel(PairArgs a) {
     constexpr int SX = CH * ET::ESZ + 16;
     constexpr int SI = C * ET::ESZ + 16;
     constexpr int XR_MAX = N1 + (K - 1) * 5;
-    constexpr int G = (ET::ESZ == 4) ? (KC >= 2 ? 2 : 1) : (KC < 4 ? KC : 4);
+    // weight-fragment prefetch depth (k16 steps). The 6-tile-wide C = 256
+    // variant at k 11 is at the 256-register limit: depth 4 spilled 4-8
+    // registers into its MFMA loop, depth 2 fits
+    constexpr int G = (ET::ESZ == 4) ? (KC >= 2 ? 2 : 1)
+                    : (KC < 4 ? KC : (NTW >= 6 && K == 11 ? 2 : 4));
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -992,9 +987,13 @@ __device__ __forceinline__ void block3_body(
     PM_STAMP(a, 14);
 }
 
+// A 4-wave whole-Block workgroup (16-bit operands) must leave room for a
+// second one on its CU: min 2 waves per SIMD caps it at 256 registers (left to
+// itself the compiler took 320 and one workgroup owned the CU: block_c64_k3
+// 1.18 ms instead of 0.81 ms, profiles/r02/ab_tile_variants.txt).
 template <class ET, int C, int K, int WM, int WN, int NTW>
 __global__ __launch_bounds__(WM * WN * 64,
-                             WM * WN == 4 && ET::ESZ == 2 ? PM_BLOCK_MINWAVES4 : 1)
+                             WM * WN == 4 && ET::ESZ == 2 ? 2 : 1)
 void conv_block3_kernel(Block3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     floatx16 unused[(C / 32) / WM][NTW];

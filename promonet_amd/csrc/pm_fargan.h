@@ -610,7 +610,9 @@ __device__ __forceinline__ void fg_slice(
         // of loads): software-pipelined in groups of FG_INFLIGHT 16-byte
         // blocks - the next group is requested before the current one is
         // used, so only the first round trip of a slice is exposed
-        constexpr int R = NB < FG_INFLIGHT ? NB : FG_INFLIGHT;
+        // (four utterances in lockstep leave registers for groups of 2)
+        constexpr int DEPTH = U >= 4 ? 2 : FG_INFLIGHT;
+        constexpr int R = NB < DEPTH ? NB : DEPTH;
         constexpr int NGROUP = (NB + R - 1) / R;
         uint4 cur[R];
 #pragma unroll

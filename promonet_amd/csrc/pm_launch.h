@@ -80,19 +80,18 @@ template <class ET, int C> struct PairCfg;
 // 192 columns per weight fetch (LDS tiles aliased to fit): the pair kernels
 // run at the power wall with the L2 94 % busy streaming weights, so fewer L2
 // bytes per MFMA is what buys clock (measured -7 % on k 7 / k 11).
-#ifdef PM_EXP_PAIR256   // experiment: 64 x 128 wave tiles, 256-column workgroup tiles
-template <> struct PairCfg<ElemF16, 256> { enum { WM = 4, WN = 2, NTW = 4, CH = 32, ALIAS = 1 }; };
-#else
+// (r02: 64 x 128 wave tiles on 256-column workgroup tiles with CH = 32 are
+// 3-5 % slower at every k - profiles/r02/ab_tile_variants.txt)
 template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 6, CH = 64, ALIAS = 1 }; };
-#endif
 // C = 128 alternatives measured and dropped: 384-column tiles with CH = 32
 // (neutral), two 4-wave 128-column workgroups per CU (neutral: L2 weight
 // traffic doubles), one fat wave per SIMD with 64 x 128 tiles (+1...+4 %).
-#ifdef PM_EXP_PAIR128   // experiment: 4 waves of 64 x 128 tiles, two workgroups per CU
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 2, WN = 2, NTW = 4, CH = 32, ALIAS = 1 }; };
-#else
+// r02: 4-wave workgroups of 64 x 128 wave tiles, two per CU (CH = 32, tiles
+// aliased) spill the staging registers and run 8-15 % slower; the same tiling
+// fed by LDS-DMA from a 16-bit copy of lrelu(x) (no staging registers, no
+// spills) is still 3-6 % slower, 8 waves on 512 columns 7-13 % slower
+// (profiles/r02/ab_pair_dma_*.txt).
 template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0 }; };
-#endif
 template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2, CH = 64, ALIAS = 0 }; };
 template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
 template <int C> struct PairCfg<ElemBF16, C> : PairCfg<ElemF16, C> {};

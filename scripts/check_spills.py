@@ -71,7 +71,12 @@ def main():
                     print(f"{k.get('vgpr_count'):>4} vgpr {k.get('agpr_count'):>3} agpr "
                           f"{k.get('sgpr_count'):>3} sgpr {k.get('group_segment_fixed_size'):>6} lds "
                           f"{spills} spill {scratch} scratch  {name}")
-                if (spills or scratch) and k['name'] not in ALLOWED:
+                # a scratch segment with no VGPR spill and some SGPR spills is
+                # the spill-slot bookkeeping of SGPRs that went to VGPR lanes:
+                # no scratch instruction is emitted for it
+                sgpr_only = not spills and int(k.get('sgpr_spill_count', 0))
+                if (spills or (scratch and not sgpr_only)) and \
+                        k['name'] not in ALLOWED:
                     bad.append((name, spills, scratch))
     if not seen:
         sys.exit('check_spills: no kernels found (build first)')

@@ -225,3 +225,85 @@ def test_fold_weight_norm(device):
         _lib.stream()))
     torch.cuda.synchronize()
     assert rel_err(out, want) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
+@pytest.mark.parametrize('channels', [32, 20])
+def test_whole_mrf(device, dtype, channels):
+    """The whole MRF ResidualBlock of the 32-channel stage in one launch
+    (Blocks k = 3, 7, 11 back to back on one tile, their sum in registers)
+    vs the oracle's residual_block (hifigan.py:141-145)."""
+    import ctypes
+    _lib = lib()
+    gen = torch.Generator().manual_seed(channels)
+    kernels, dilations = (3, 7, 11), (1, 3, 5)
+    state, order = {}, {'w1': [], 'b1': [], 'w2': [], 'b2': []}
+    for j, k in enumerate(kernels):
+        std = 1. / (channels * k) ** .5
+        for n in range(3):
+            for which in (1, 2):
+                w = torch.randn(channels, channels, k, generator=gen) * std
+                b = torch.randn(channels, generator=gen) * .1
+                state[f'p.model.{j}.convs{which}.{n}.weight'] = w
+                state[f'p.model.{j}.convs{which}.{n}.bias'] = b
+                order[f'w{which}'].append(w.to(device).contiguous())
+                order[f'b{which}'].append(b.to(device).contiguous())
+
+    def pointers(name):
+        return (ctypes.c_void_p * 9)(*[t.data_ptr() for t in order[name]])
+
+    dil = (ctypes.c_int * 3)(*dilations)
+    ws = torch.empty(
+        9 * _lib.lib().pm_op_workspace_bytes(channels, channels, 11),
+        dtype=torch.uint8, device=device)
+    for length in (900, 1, 61, 1500):
+        x = torch.randn(2, channels, length, generator=gen)
+        want = oracle.residual_block(x, state, 'p')
+        x_cl = to_cl(x).to(device)
+        out = torch.full_like(x_cl, 7.)
+        _lib.check(_lib.lib().pm_mrf_cl(
+            _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out), pointers('w1'),
+            pointers('b1'), pointers('w2'), pointers('b2'), dil, 3, 2, length,
+            channels, ws.data_ptr(), ws.numel(), _lib.stream()))
+        torch.cuda.synchronize()
+        got = from_cl(out, channels).cpu()
+        assert rel_err(got, want) < 2 * TOL[dtype], (length, dtype)
+    with pytest.raises(RuntimeError):
+        x_cl = torch.zeros(1, 8, 64, device=device)
+        _lib.check(_lib.lib().pm_mrf_cl(
+            _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(x_cl), pointers('w1'),
+            pointers('b1'), pointers('w2'), pointers('b2'), dil, 3, 1, 8, 64,
+            ws.data_ptr(), ws.numel(), _lib.stream()))
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'f16'])
+@pytest.mark.parametrize('shape', [(113, 512, 258), (113, 64, 258), (40, 32, 6)])
+def test_input_conv(device, dtype, shape):
+    """Input feature conv (k 7) + speaker conditioning conv (k 1) as a
+    per-utterance bias (hifigan.py:19-30, 67-68), batch-1 globals broadcast."""
+    _lib = lib()
+    c_in, c_out, G = shape
+    gen = torch.Generator().manual_seed(c_in + c_out)
+    w = torch.randn(c_out, c_in, 7, generator=gen) / (c_in * 7) ** .5
+    bias = torch.randn(c_out, generator=gen) * .1
+    sw = torch.randn(c_out, G, 1, generator=gen) / G ** .5
+    sb = torch.randn(c_out, generator=gen) * .1
+    on_device = [t.to(device).contiguous() for t in (w, bias, sw, sb)]
+    for batch, length, gbatch in ((2, 45, 2), (3, 130, 1), (1, 1, 1)):
+        x = torch.randn(batch, c_in, length, generator=gen)
+        g = torch.randn(gbatch, G, 1, generator=gen)
+        want = F.conv1d(x, w, bias, padding=3) + F.conv1d(g, sw, sb)
+        x_cl = to_cl(x).to(device)
+        out = torch.zeros(batch, length, pad32(c_out), device=device)
+        glob = g[:, :, 0].to(device).contiguous()
+        size = _lib.lib().pm_op_workspace_bytes(c_in, c_out, 7) + \
+            256 * ((batch * pad32(c_out) * 4 + 255) // 256)
+        ws = torch.empty(size, dtype=torch.uint8, device=device)
+        _lib.check(_lib.lib().pm_input_conv_cl(
+            _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out),
+            *[_lib.ptr(t) for t in on_device[:2]], _lib.ptr(glob),
+            *[_lib.ptr(t) for t in on_device[2:]], gbatch, G, batch, length,
+            c_in, c_out, ws.data_ptr(), ws.numel(), _lib.stream()))
+        torch.cuda.synchronize()
+        got = from_cl(out, c_out).cpu()
+        assert rel_err(got, want) < TOL[dtype], (batch, length)
