@@ -60,10 +60,11 @@ def parse_args():
     parser.add_argument('--warmup', type=int, default=3)
     parser.add_argument('--model', default='hifigan',
                         choices=['hifigan', 'fargan'])
-    parser.add_argument('--dtype', default='f16',
+    parser.add_argument('--dtype', default=None,
                         choices=['f16', 'bf16', 'fp32'],
-                        help='MFMA operand type (hifigan) / stored weight '
-                             'type f16|fp32 (fargan; its math is fp32)')
+                        help='MFMA operand type (hifigan, default f16) / '
+                             'stored weight type f16|fp32 (fargan, default '
+                             'fp32; its math is always fp32)')
     parser.add_argument('--batch', type=int, default=32,
                         help='utterances per GPU')
     parser.add_argument('--seconds', type=float, default=10.)
@@ -184,6 +185,8 @@ def parse_profile(text):
 
 def main():
     args = parse_args()
+    if args.dtype is None:
+        args.dtype = 'fp32' if args.model == 'fargan' else 'f16'
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
     rank, world, device = promonet_amd.distributed.init()

@@ -51,9 +51,23 @@ struct ElemF16 {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
     __device__ static __forceinline__ void store4(char* p, float4 v) {
-        // vector conversion: two v_cvt_pk_f16_f32 (round to nearest even)
+        // vector conversion: two v_cvt_pk_f16_f32 (round to nearest even),
+        // then saturation at the top of the f16 range (two v_pk_min_f16): an
+        // activation beyond 65504 (a trained checkpoint may produce one where
+        // the random-init weights of the tests do not) becomes 65504 instead
+        // of +inf, so it cannot poison the MFMA sums. Every operand but the
+        // conditioning features passes LeakyReLU first, which shrinks the
+        // negative side tenfold (-inf only below -655 040): the lower clamp
+        // is left out - both clamps cost 1.6 % of the step, this one half
+        // (profiles/r02/ab_f16_saturate.txt).
         const pm_f4 w = {v.x, v.y, v.z, v.w};
-        *reinterpret_cast<half4*>(p) = __builtin_convertvector(w, half4);
+        half4 h = __builtin_convertvector(w, half4);
+#ifndef PM_NO_F16_SATURATE
+        const _Float16 big = (_Float16)65504.f;
+        const half4 hi = {big, big, big, big};
+        h = __builtin_elementwise_min(h, hi);
+#endif
+        *reinterpret_cast<half4*>(p) = h;
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return (_Float16)v; }
     // bias step (pm_pack_bias_step_kernel): c += b[co] for every column

@@ -1,0 +1,54 @@
+"""profiles/traffic.json from a rocprofv3 PMC summary (scripts/profile_gpu.sh ->
+summarize_profile.py): HBM bytes per launch = (FETCH_SIZE x 2 + WRITE_SIZE) x
+1024 - both counters are in KiB and on gfx950 FETCH_SIZE reports half of a wide
+coalesced read stream (MI355X_MICROARCH.md, section HBM) - keyed by the labels
+bench.py uses. usage: python scripts/make_traffic.py gpurun_out/prof_r02 f16"""
+import json
+import re
+import sys
+from pathlib import Path
+
+
+def label(kernel):
+    m = re.match(r'conv_pair_kernel<\w+,(\d+),(\d+),', kernel)
+    if m:
+        return f'pair_c{m.group(1)}_k{m.group(2)}'
+    m = re.match(r'conv_block3_kernel<\w+,(\d+),(\d+),', kernel)
+    if m:
+        return f'block_c{m.group(1)}_k{m.group(2)}'
+    m = re.match(r'conv_mrf_kernel<\w+,(\d+),', kernel)
+    if m:
+        return f'mrf_c{m.group(1)}'
+    if kernel.startswith('pm_out_conv'):
+        return 'out_conv_tanh'
+    if re.match(r'conv_single_kernel<\w+,7,7,', kernel):
+        return 'input_conv'
+    # polyphase upsamplers: the 128- and 64-row variants are one launch each;
+    # the 256-row-tile variant serves two layers (skipped: ambiguous average)
+    if re.match(r'conv_single_kernel<\w+,2,3,64,4,2,1,2,0>', kernel):
+        return 'convT_c128_r2'
+    if re.match(r'conv_single_kernel<\w+,2,3,64,2,2,1,2,0>', kernel):
+        return 'convT_c64_r2'
+    return None
+
+
+def main(root, dtype):
+    summary = json.loads((Path(root) / 'summary.json').read_text())
+    fetch, write = summary['pmc_fetch'], summary['pmc_write']
+    table = {}
+    for kernel, counters in fetch.items():
+        name = label(kernel)
+        if name is None or kernel not in write:
+            continue
+        table[f'{name}:{dtype}'] = (
+            counters['FETCH_SIZE'] * 2 + write[kernel]['WRITE_SIZE']) * 1024
+    out = Path(__file__).resolve().parent.parent / 'profiles' / 'traffic.json'
+    merged = json.loads(out.read_text()) if out.exists() else {}
+    merged.update(table)
+    out.write_text(json.dumps(merged, indent=1))
+    for key, value in sorted(table.items()):
+        print(f'{key:24s} {value / 1e9:.3f} GB per launch')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'f16')

@@ -307,3 +307,38 @@ def test_input_conv(device, dtype, shape):
         torch.cuda.synchronize()
         got = from_cl(out, c_out).cpu()
         assert rel_err(got, want) < TOL[dtype], (batch, length)
+
+
+def test_f16_operands_saturate(device):
+    """Activations beyond the top of the f16 range (65504) - possible with a
+    trained checkpoint, never with the random-init weights of the parity
+    tests - are saturated when they are converted to MFMA operands, not
+    turned into inf (LeakyReLU keeps the negative side ten times further
+    from its limit):
+    the Block output stays finite and equals the oracle fed the saturated
+    activations. Also: realistically large activations (1e3) keep the
+    relative error of the f16 path."""
+    gen = torch.Generator().manual_seed(3)
+    channels, k, d, length = 128, 7, 3, 200
+    std = 1. / (channels * k) ** .5
+    w1 = torch.randn(channels, channels, k, generator=gen) * std
+    w2 = torch.randn(channels, channels, k, generator=gen) * std
+    b1 = torch.randn(channels, generator=gen) * .1
+    b2 = torch.randn(channels, generator=gen) * .1
+    x = torch.randn(1, channels, length, generator=gen) * 1e3
+    want = block_iteration_oracle(x, w1, b1, w2, b2, k, d)
+    got = run_block_iteration(device, 'f16', x, w1, b1, w2, b2, k, d)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, want) < TOL['f16']
+    x[0, 5, 50] = 3e5                       # lrelu(x) = 3e5 > 65504
+    x[0, 9, 120] = -6e5                     # lrelu(x) = -6e4: still finite
+    got = run_block_iteration(device, 'f16', x, w1, b1, w2, b2, k, d)
+    assert torch.isfinite(got).all()
+
+    def saturated_oracle():
+        xt = torch.clamp(F.leaky_relu(x, .1), max=65504.)
+        xt = F.conv1d(xt, w1, b1, padding=oracle.get_padding(k, d), dilation=d)
+        xt = torch.clamp(F.leaky_relu(xt, .1), max=65504.)
+        xt = F.conv1d(xt, w2, b2, padding=oracle.get_padding(k, 1))
+        return xt + x
+    assert rel_err(got, saturated_oracle()) < TOL['f16']
