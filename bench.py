@@ -62,7 +62,7 @@ def parse_args():
                         choices=['hifigan', 'fargan'])
     parser.add_argument('--dtype', default=None,
                         choices=['f16', 'bf16', 'fp32'],
-                        help='MFMA operand type (hifigan, default f16) / '
+                        help='MFMA operand type (hifigan, default bf16) / '
                              'stored weight type f16|fp32 (fargan, default '
                              'fp32; its math is always fp32)')
     parser.add_argument('--batch', type=int, default=32,
@@ -186,7 +186,8 @@ def parse_profile(text):
 def main():
     args = parse_args()
     if args.dtype is None:
-        args.dtype = 'fp32' if args.model == 'fargan' else 'f16'
+        args.dtype = 'fp32' if args.model == 'fargan' else \
+            promonet_amd.config.DEFAULT_COMPUTE_DTYPE
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
     rank, world, device = promonet_amd.distributed.init()
@@ -353,12 +354,6 @@ def main():
             'samples_per_sec_per_gpu': per_gpu,
             'rtf_per_gpu': per_gpu / promonet_amd.SAMPLE_RATE,
         }
-        if not fargan and args.dtype == 'f16':
-            result['dtype_note'] = (
-                'BASELINE.json configs[2] names bf16; f16 operands run at the '
-                'same MFMA rate and byte width and meet the 1e-4 max-abs gate '
-                '(tests/test_gpu_model.py::test_full_size_*), plain bf16 '
-                'operands do not (DESIGN.md section 3); --dtype bf16 runs them')
         if sustained:
             seconds, count = sustained
             result['sustained_ms_per_step'] = seconds / count * 1e3

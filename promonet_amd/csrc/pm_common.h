@@ -69,6 +69,12 @@ struct ElemF16 {
 #endif
         *reinterpret_cast<half4*>(p) = h;
     }
+    // four fp32 -> four operand values in two dwords (saturating, as store4)
+    __device__ static __forceinline__ uint2 pack4(float4 v) {
+        uint2 r;
+        store4(reinterpret_cast<char*>(&r), v);
+        return r;
+    }
     __device__ static __forceinline__ lds_t cvt(float v) { return (_Float16)v; }
     // bias step (pm_pack_bias_step_kernel): c += b[co] for every column
     __device__ static __forceinline__ void mma_bias(
@@ -91,6 +97,10 @@ struct ElemBF16 {
     __device__ static __forceinline__ void store4(char* p, float4 v) {
         const pm_f4 w = {v.x, v.y, v.z, v.w};
         *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(w, bf16x4);
+    }
+    __device__ static __forceinline__ uint2 pack4(float4 v) {
+        const pm_f4 w = {v.x, v.y, v.z, v.w};
+        return __builtin_bit_cast(uint2, __builtin_convertvector(w, bf16x4));
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return (__bf16)v; }
     __device__ static __forceinline__ void mma_bias(

@@ -228,6 +228,62 @@ __device__ __forceinline__ float4 acc_quad(const floatx16& v, const int g4) {
     return make_float4(v[4 * g4], v[4 * g4 + 1], v[4 * g4 + 2], v[4 * g4 + 3]);
 }
 
+// One 32 x 32 accumulator tile -> LDS rows in the operand type, LeakyReLU
+// fused, zeroed where `zero` (columns outside the utterance). In the C/D
+// layout a lane holds 4 consecutive channels per register quad and lane
+// l + 32 the next 4: two quads are exchanged across the half-waves
+// (v_permlane32_swap) so that every lane owns 8 consecutive channels and
+// stores 16 bytes. ds_write_b128 is served in 8-lane groups whose rows, at a
+// row stride of 16 x odd bytes, cover the 32 banks exactly once; the 8-byte
+// stores this replaces were 2-way conflicted (rows r and r + 8 on one bank:
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 18-20 % in the whole-Block kernels).
+// `rowp` = the lane's row in the LDS tile, `ch` = the tile's first channel.
+template <class ET, bool MASK>
+__device__ __forceinline__ void store_tile_lrelu_impl(
+    char* rowp, const int ch, const floatx16& v, const bool zero,
+    const int lh) {
+    if constexpr (ET::ESZ == 2) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4 += 2) {
+            float4 lo = pm_lrelu4(acc_quad(v, g4));
+            float4 hi = pm_lrelu4(acc_quad(v, g4 + 1));
+            if (MASK && zero) {
+                lo = make_float4(0.f, 0.f, 0.f, 0.f);
+                hi = lo;
+            }
+            uint2 a = ET::pack4(lo), b = ET::pack4(hi);
+            auto sx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+            auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+            // lanes < 32: [own quad g4 | upper half's quad g4] = channels
+            // 8 g4 .. 8 g4 + 7; lanes >= 32: [lower's g4 + 1 | own g4 + 1]
+            *reinterpret_cast<uint4*>(rowp + (ch + 8 * (g4 + lh)) * 2) =
+                make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+    } else {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float4 q = pm_lrelu4(acc_quad(v, g4));
+            if (MASK && zero) q = make_float4(0.f, 0.f, 0.f, 0.f);
+            ET::store4(rowp + (ch + 8 * g4 + 4 * lh) * ET::ESZ, q);
+        }
+    }
+}
+
+// `t_tile` = time of the tile's first column: the zero-padding mask (columns
+// outside [0, L)) only runs on tiles that straddle an utterance edge - a
+// wave-uniform branch, both sides executed with all lanes active.
+template <class ET>
+__device__ __forceinline__ void store_tile_lrelu(
+    char* rowp, const int ch, const floatx16& v, const int t_tile,
+    const int L, const int ln, const int lh) {
+    if (t_tile >= 0 && t_tile + 32 <= L) {
+        store_tile_lrelu_impl<ET, false>(rowp, ch, v, false, lh);
+    } else {
+        const int t = t_tile + ln;
+        store_tile_lrelu_impl<ET, true>(rowp, ch, v, !(t >= 0 && t < L), lh);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Fused Block iteration
 // ---------------------------------------------------------------------------
@@ -367,27 +423,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     load_bias_frags<ET, MTW>(bf, w2 + W_BIAS, W_MT_STRIDE);
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-        const int co_base = (wm * MTW + mt) * 32 + 4 * lh;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int n_first = (wn * NTW + nt) * 32;
             const int n = n_first + ln;
             const int t_tile = t0 - H2 + n_first;
-            if (t_tile >= 0 && t_tile + 32 <= L) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    ET::store4(inter + n * SI + (co_base + 8 * g4) * ET::ESZ,
-                               pm_lrelu4(acc_quad(acc[mt][nt], g4)));
-            } else {
-                const int t = t_tile + ln;
-                const bool inside = (t >= 0) && (t < L);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float4 v = pm_lrelu4(acc_quad(acc[mt][nt], g4));
-                    if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    ET::store4(inter + n * SI + (co_base + 8 * g4) * ET::ESZ, v);
-                }
-            }
+            store_tile_lrelu<ET>(inter + n * SI, (wm * MTW + mt) * 32,
+                                 acc[mt][nt], t_tile, L, ln, lh);
         }
     }
     bias_start<ET, MTW, NTW>(acc, bf);
@@ -801,12 +843,9 @@ __device__ __forceinline__ void block3_body(
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int col = (wn * NTW + nt) * 32 + ln;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                ET::store4(
-                    abuf + (MA + col) * S +
-                        (m_first + mt * 32 + 8 * g4 + 4 * lh) * ET::ESZ,
-                    pm_lrelu4(acc_quad(trunk[mt][nt], g4)));
+            store_tile_lrelu_impl<ET, false>(
+                abuf + (MA + col) * S, m_first + mt * 32, trunk[mt][nt], false,
+                lh);
         }
     __syncthreads();
     PM_STAMP(a, 1);
@@ -847,26 +886,8 @@ __device__ __forceinline__ void block3_body(
                 const int col_first = (wn * NTW + nt) * 32;
                 const int col = col_first + ln;
                 const int t_tile = c_first + col_first;
-                if (t_tile >= 0 && t_tile + 32 <= L) {
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4)
-                        ET::store4(
-                            tbuf + (H2 + col) * S +
-                                (m_first + mt * 32 + 8 * g4 + 4 * lh) * ET::ESZ,
-                            pm_lrelu4(acc_quad(acc[mt][nt], g4)));
-                } else {
-                    const int t = t_tile + ln;
-                    const bool inside = t >= 0 && t < L;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        float4 v = pm_lrelu4(acc_quad(acc[mt][nt], g4));
-                        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        ET::store4(
-                            tbuf + (H2 + col) * S +
-                                (m_first + mt * 32 + 8 * g4 + 4 * lh) * ET::ESZ,
-                            v);
-                    }
-                }
+                store_tile_lrelu<ET>(tbuf + (H2 + col) * S, m_first + mt * 32,
+                                     acc[mt][nt], t_tile, L, ln, lh);
             }
         // ---- conv2 (dilation 1) out of `t`, accumulated IN PLACE onto the
         // fp32 trunk (the residual add is the MFMA's C operand) ----
@@ -899,28 +920,9 @@ __device__ __forceinline__ void block3_body(
                     const int col_first = (wn * NTW + nt) * 32;
                     const int col = col_first + ln;
                     const int t_tile = c_first + col_first;
-                    if (t_tile >= 0 && t_tile + 32 <= L) {
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4)
-                            ET::store4(
-                                abuf + (MA + col) * S +
-                                    (m_first + mt * 32 + 8 * g4 + 4 * lh) *
-                                        ET::ESZ,
-                                pm_lrelu4(acc_quad(trunk[mt][nt], g4)));
-                    } else {
-                        const int t = t_tile + ln;
-                        const bool inside = t >= 0 && t < L;
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            float4 v = pm_lrelu4(acc_quad(trunk[mt][nt], g4));
-                            if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                            ET::store4(
-                                abuf + (MA + col) * S +
-                                    (m_first + mt * 32 + 8 * g4 + 4 * lh) *
-                                        ET::ESZ,
-                                v);
-                        }
-                    }
+                    store_tile_lrelu<ET>(abuf + (MA + col) * S,
+                                         m_first + mt * 32, trunk[mt][nt],
+                                         t_tile, L, ln, lh);
                 }
             }
         if (!last) bias_start<ET, MTW, NTW>(acc, bf);

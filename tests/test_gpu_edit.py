@@ -89,7 +89,8 @@ def test_edit_then_synthesize_stays_on_device(device, golden_default):
         model = promonet_amd.model.Generator()
         model.load_state_dict(state)
     finally:
-        promonet_amd.configure(COMPUTE_DTYPE='f16')
+        promonet_amd.configure(
+            COMPUTE_DTYPE=promonet_amd.config.DEFAULT_COMPUTE_DTYPE)
     promonet_amd.synthesize.set_model(model, device)
     inputs = oracle.synthetic_inputs(1, 30, seed=2)
     args = [inputs[0][0], inputs[1], inputs[2], inputs[3][0]]
