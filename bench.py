@@ -307,7 +307,7 @@ def main():
         total_samples = world * samples_per_step * args.steps
         value = total_samples / elapsed
         per_gpu = value / world
-        dtype = ('f32' if fargan else args.dtype)
+        dtype = 'fp32' if fargan else args.dtype   # the arithmetic type
         if fargan:
             workload = (
                 f'Generator.forward (prepare_features + FARGAN, '

@@ -95,14 +95,16 @@ def test_long_sequence_vs_oracle(device, fargan_model):
     assert max_abs(got, want) < 2e-5
 
 
-@pytest.mark.parametrize('mode', [1, 2])
-def test_full_size_config5(device, fargan_model, mode):
+@pytest.mark.parametrize('dtype,mode', [('fp32', 1), ('fp32', 2), ('f16', 2)])
+def test_full_size_config5(device, fargan_model, dtype, mode):
     """BASELINE.json configs[4] at full size: batch 32 x 861 frames (3 444
     dependent sub-frame steps - where autoregressive drift would show).
     Utterances 3 and 30 are checked over their WHOLE length against the CPU
     oracle at the 1e-4 gate, in both kernel modes; the rest through the
-    size-independent property (modes agree, runs are deterministic)."""
-    model = fargan_model('fp32')
+    size-independent property (modes agree, runs are deterministic). With
+    f16-STORED weights (fp32 arithmetic) the error is 7e-5 and does not grow
+    along the 3 444 autoregressive steps: same gate."""
+    model = fargan_model(dtype)
     inputs = oracle.synthetic_inputs(32, 861, seed=55)
     pick = [3, 30]
     with torch.inference_mode():
@@ -114,7 +116,7 @@ def test_full_size_config5(device, fargan_model, mode):
     assert got.shape == (32, 1, 861 * 256) and torch.isfinite(got).all()
     error = max_abs(got[pick], want)
     tail = max_abs(got[pick][..., -256 * 40:], want[..., -256 * 40:])
-    print(f'fargan full size mode {mode}: max-abs {error:.3e} (last 40 '
+    print(f'fargan full size {dtype} mode {mode}: max-abs {error:.3e} (last 40 '
           f'frames {tail:.3e}; abs-max {want.abs().max().item():.3f})')
     assert error < 1e-4
 
