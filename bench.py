@@ -109,29 +109,31 @@ def synthetic_inputs(batch, frames, seed, device):
 
 def cpu_baseline(model_name, budget=40.):
     """The CPU oracle (a port of the reference's op sequence in PyTorch fp32)
-    timed on this host's cores at os.cpu_count() torch threads and at 8
+    timed on this host's cores at 8 torch threads and at os.cpu_count()
     (SURVEY.md section 8(d)): median of 3 runs after a warm-up, on a sample of
     BASELINE.json config 2's shape (batch 8 x 5 s; FARGAN: batch 2) that a
-    short probe sizes so that each thread setting gets about budget / 2
-    seconds of CPU work - a many-core host with a slow all-core setting then
-    times a smaller batch instead of stalling the bench. A reported baseline,
-    not the target."""
+    short probe sizes so that each setting gets about budget / 2 seconds. A
+    setting whose 8-frame probe alone takes seconds (all 256 threads of a big
+    host on these small convolutions: oversubscribed, 1000x slower than 8
+    threads) is reported from that probe and not run further, so the bench
+    stays within a few minutes. A reported baseline, not the target."""
     sys.path.insert(0, str(ROOT / 'oracle'))
     import restatement as oracle
     if model_name == 'fargan':
-        full_batch, full_frames, probe_frames = 2, 430, 6
+        full_batch, full_frames = 2, 430
         state = oracle.random_state_fargan(seed=0)
         forward = oracle.fargan_generator_forward
         name = 'fargan_generator_forward'
     else:
-        full_batch, full_frames, probe_frames = 8, 430, 43
+        full_batch, full_frames = 8, 430
         state = oracle.random_state(seed=0)
         forward = oracle.generator_forward
         name = 'generator_forward'
     hop = promonet_amd.HOPSIZE
+    probe_frames = 8
     cpus = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    settings = sorted({cpus, min(8, cpus)}, reverse=True)
+    settings = sorted({min(8, cpus), cpus})
     slot = budget / len(settings)
 
     def run(batch, frames):
@@ -141,21 +143,32 @@ def cpu_baseline(model_name, budget=40.):
         return time.perf_counter() - start
 
     by_threads, sample_by_threads = {}, {}
-    spent = 0.
+    begin = time.perf_counter()
     with torch.inference_mode():
         for threads in settings:
             torch.set_num_threads(threads)
-            begin = time.perf_counter()
-            run(1, probe_frames)                                  # warm-up
-            rate = probe_frames * hop / run(1, probe_frames)      # probe
+            warm = run(1, probe_frames)                           # warm-up
+            if warm > slot / 4:
+                by_threads[threads] = probe_frames * hop / warm
+                sample_by_threads[threads] = \
+                    f'1 x {probe_frames} frames, the warm-up run only'
+                continue
+            probe = run(1, probe_frames)
+            rate = probe_frames * hop / probe
             # largest (batch, frames) <= config 2's whose 3 runs fit the slot
-            affordable = rate * slot / 3.5 / hop                  # frames
+            affordable = rate * (slot - warm - probe) / 3.3 / hop     # frames
+            if affordable < 2 * probe_frames:
+                by_threads[threads] = rate
+                sample_by_threads[threads] = \
+                    f'1 x {probe_frames} frames, single run'
+                continue
             batch = int(min(full_batch, max(1, affordable // full_frames)))
-            frames = int(min(full_frames, max(probe_frames, affordable // batch)))
+            frames = int(min(full_frames, affordable // batch))
             times = [run(batch, frames) for _ in range(3)]
             by_threads[threads] = batch * frames * hop / statistics.median(times)
-            sample_by_threads[threads] = f'{batch} x {frames} frames'
-            spent += time.perf_counter() - begin
+            sample_by_threads[threads] = \
+                f'{batch} x {frames} frames, median of 3'
+    spent = time.perf_counter() - begin
     torch.set_num_threads(default_threads)
     threads = max(by_threads, key=by_threads.get)
     return {
@@ -165,12 +178,11 @@ def cpu_baseline(model_name, budget=40.):
         'samples_per_s_by_threads': by_threads,
         'sample_by_threads': sample_by_threads,
         'sample': f'oracle/restatement.py {name} (PyTorch CPU port of the '
-                  f'reference op sequence), fp32, median of 3 runs after a '
-                  f'warm-up at {sorted(by_threads)} torch threads on {cpus} '
-                  f'cpus, batch x frames per setting sized by a probe to '
-                  f'~{slot:.0f} s each ({sample_by_threads}; config 2 is '
-                  f'{full_batch} x {full_frames}); {spent:.0f} s of CPU work; '
-                  f'value = the faster setting'}
+                  f'reference op sequence), fp32, at {sorted(by_threads)} torch '
+                  f'threads on {cpus} cpus; per setting a probe sizes the '
+                  f'sample ({sample_by_threads}; config 2 is {full_batch} x '
+                  f'{full_frames}); {spent:.0f} s of CPU work; value = the '
+                  f'faster setting'}
 
 
 def parse_profile(text):
