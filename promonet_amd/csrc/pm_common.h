@@ -138,6 +138,22 @@ struct ElemF32 {
     }
 };
 
+// Workgroup barrier for kernels whose threads talk through LDS only.
+// __syncthreads() fences every address space: the compiler puts
+// s_waitcnt vmcnt(0) in front of the s_barrier, i.e. every global load in
+// flight (the next weight group, the next staged chunk, the residual) has to
+// land before the wave may even ARRIVE. Fencing the LDS alone keeps those
+// loads in flight across the barrier.
+__device__ __forceinline__ void pm_block_sync() {
+#ifdef PM_EXP_NO_LDSBAR
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+
 // Bijective XCD-aware remap of a linear workgroup id: the dispatcher places
 // block b on XCD b % 8; give each XCD a contiguous run of tiles so that
 // neighbouring time tiles (which share halo rows) hit the same L2.

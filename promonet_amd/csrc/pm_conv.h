@@ -321,7 +321,9 @@ __host__ __device__ constexpr int pair_smem_bytes(int d) {
 }
 
 template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS>
-__global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
+__global__ __launch_bounds__(WM * WN * 64,
+                             WM * WN == 4 && ET::ESZ == 2 ? 2 : 1)
+void conv_pair_kernel(
     PairArgs a) {
     typedef typename ET::frag_t frag_t;
     constexpr int NCH = C / CH;
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     ChunkStager<ET, CH, NT, XR_MAX> stager;
     stager.load(xb, C, 0, t_first, XR, L, tid);
     stager.template store<true>(xbuf, XR, tid);
-    __syncthreads();
+    pm_block_sync();
     PM_STAMP(a, 1);
     bias_start<ET, MTW, NTW>(acc, bf);
 
@@ -410,16 +412,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
             stage_next);
         if (c < 2) PM_STAMP(a, 6 + 3 * c);
         if (more) {
-            __syncthreads();
+            pm_block_sync();
             if (c < 2) PM_STAMP(a, 8 + 3 * c);
         }
     }
 
     PM_STAMP(a, 2);
-    if (ALIAS) __syncthreads();     // every wave is done with the x chunks
+    if (ALIAS) pm_block_sync();     // every wave is done with the x chunks
     // ---------------- epilogue 1: lrelu, zero-pad mask -> LDS --------------
     // (bias already in the accumulator; the mask only on tiles that straddle
     // an utterance edge - a wave-uniform branch)
+    // The residual rides in the accumulator: as soon as a tile's conv1
+    // result is in LDS its registers take the fp32 trunk x of the conv2
+    // output tile (same C/D layout), conv2 accumulates on top of it and
+    // epilogue 2 only stores. The loads fly across the barrier
+    // (pm_block_sync fences LDS only) instead of costing one HBM round trip
+    // per 32 x 32 tile between conv2 and the stores.
     load_bias_frags<ET, MTW>(bf, w2 + W_BIAS, W_MT_STRIDE);
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
@@ -430,10 +438,31 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
             const int t_tile = t0 - H2 + n_first;
             store_tile_lrelu<ET>(inter + n * SI, (wm * MTW + mt) * 32,
                                  acc[mt][nt], t_tile, L, ln, lh);
+#ifndef PM_EXP_NO_RESACC
+            // (columns beyond the tile / the utterance are never stored:
+            // they load a valid row and their sums are don't-cares)
+            const int t = min(t0 + n, L - 1);
+            const float* xr = xb + (size_t)t * C +
+                              (wm * MTW + mt) * 32 + 4 * lh;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 r = *reinterpret_cast<const float4*>(xr + 8 * g4);
+                acc[mt][nt][4 * g4 + 0] = r.x;
+                acc[mt][nt][4 * g4 + 1] = r.y;
+                acc[mt][nt][4 * g4 + 2] = r.z;
+                acc[mt][nt][4 * g4 + 3] = r.w;
+            }
+#endif
         }
     }
+#ifdef PM_EXP_NO_RESACC
     bias_start<ET, MTW, NTW>(acc, bf);
-    __syncthreads();
+    pm_block_sync();
+#else
+    pm_block_sync();
+    __builtin_amdgcn_sched_barrier(0);   // the bias MFMAs wait for the loads:
+    bias_add<ET, MTW, NTW>(acc, bf);     // keep them behind the barrier
+#endif
     PM_STAMP(a, 3);
 
     // ---------------- conv2 (dilation 1) straight out of LDS ---------------
@@ -454,6 +483,69 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     float* __restrict__ ob = a.out + (size_t)b * a.L * C;
     const int mode = a.mode;
     const float scale = a.scale;
+#ifndef PM_EXP_NO_RESACC
+    if (mode == 2) {
+        // MRF accumulation: every read of `out` is issued before the first
+        // store (one round trip for the whole wave tile; the operand
+        // fragment registers are dead by now)
+        float4 old[MTW][NTW][4];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = (wn * NTW + nt) * 32 + ln;
+                const int t = t0 + n;
+                const bool live = n < TL && t < L;
+                const float* orow = ob + (size_t)(live ? t : 0) * C +
+                                    (wm * MTW + mt) * 32 + 4 * lh;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    old[mt][nt][g4] =
+                        *reinterpret_cast<const float4*>(orow + 8 * g4);
+            }
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = (wn * NTW + nt) * 32 + ln;
+                const int t = t0 + n;
+                if (n < TL && t < L) {
+                    float* orow = ob + (size_t)t * C +
+                                  (wm * MTW + mt) * 32 + 4 * lh;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 o = old[mt][nt][g4];
+                        float4 v;
+                        v.x = o.x + acc[mt][nt][4 * g4 + 0] * scale;
+                        v.y = o.y + acc[mt][nt][4 * g4 + 1] * scale;
+                        v.z = o.z + acc[mt][nt][4 * g4 + 2] * scale;
+                        v.w = o.w + acc[mt][nt][4 * g4 + 3] * scale;
+                        *reinterpret_cast<float4*>(orow + 8 * g4) = v;
+                    }
+                }
+            }
+    } else {
+        const float s = mode == 1 ? scale : 1.f;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = (wn * NTW + nt) * 32 + ln;
+                const int t = t0 + n;
+                if (n < TL && t < L) {
+                    float* orow = ob + (size_t)t * C +
+                                  (wm * MTW + mt) * 32 + 4 * lh;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<float4*>(orow + 8 * g4) =
+                            make_float4(acc[mt][nt][4 * g4 + 0] * s,
+                                        acc[mt][nt][4 * g4 + 1] * s,
+                                        acc[mt][nt][4 * g4 + 2] * s,
+                                        acc[mt][nt][4 * g4 + 3] * s);
+                }
+            }
+    }
+#else
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         const int co_base = (wm * MTW + mt) * 32 + 4 * lh;
@@ -493,6 +585,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
             }
         }
     }
+#endif
     PM_STAMP(a, 5);
 }
 
@@ -588,7 +681,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
     stager.load(xb, Cin, 0, t_first, XR, L, tid);
     if (a.lrelu) stager.template store<true>(smem, XR, tid);
     else stager.template store<false>(smem, XR, tid);
-    __syncthreads();
+    pm_block_sync();
 
     const int w_mt_stride = NCH * KT * KC * 64;
     const frag_t* w = reinterpret_cast<const frag_t*>(a.w) +
@@ -611,7 +704,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
             char* nxt = smem + ((c + 1) & 1) * XR * SX;
             if (a.lrelu) stager.template store<true>(nxt, XR, tid);
             else stager.template store<false>(nxt, XR, tid);
-            __syncthreads();
+            pm_block_sync();
         }
     }
 
@@ -847,7 +940,7 @@ __device__ __forceinline__ void block3_body(
                 abuf + (MA + col) * S, m_first + mt * 32, trunk[mt][nt], false,
                 lh);
         }
-    __syncthreads();
+    pm_block_sync();
     PM_STAMP(a, 1);
 
     const int col_off = (wn * NTW * 32 + ln) * S + lh * 8 * ET::ESZ;
@@ -892,7 +985,7 @@ __device__ __forceinline__ void block3_body(
         // ---- conv2 (dilation 1) out of `t`, accumulated IN PLACE onto the
         // fp32 trunk (the residual add is the MFMA's C operand) ----
         bias_add<ET, MTW, NTW>(trunk, bf);
-        __syncthreads();
+        pm_block_sync();
         PM_STAMP(a, 3 + 4 * it);
 
         const bool last = it + 1 == a.niter;
@@ -926,7 +1019,7 @@ __device__ __forceinline__ void block3_body(
                 }
             }
         if (!last) bias_start<ET, MTW, NTW>(acc, bf);
-        if (!last) __syncthreads();
+        if (!last) pm_block_sync();
         PM_STAMP(a, 5 + 4 * it);
     }
 
@@ -1020,15 +1113,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_kernel(MrfArgs m) {
         // `out`); k = 11 first: its MFMA loop has the highest register
         // pressure and runs before the sum is live
         block3_body<ET, C, 11, WM, WN, NTW, 1>(m.k[2], smem, sum);
-        __syncthreads();
+        pm_block_sync();
         block3_body<ET, C, 7, WM, WN, NTW, 2>(m.k[1], smem, sum);
-        __syncthreads();
+        pm_block_sync();
         block3_body<ET, C, 3, WM, WN, NTW, 3>(m.k[0], smem, sum);
     } else {
         block3_body<ET, C, 3, WM, WN, NTW>(m.k[0], smem, sum);
-        __syncthreads();
+        pm_block_sync();
         block3_body<ET, C, 7, WM, WN, NTW>(m.k[1], smem, sum);
-        __syncthreads();
+        pm_block_sync();
         block3_body<ET, C, 11, WM, WN, NTW>(m.k[2], smem, sum);
     }
 }

@@ -1,0 +1,7 @@
+#!/bin/bash
+# A/B: LDS-only barriers, residual through the accumulator
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+OUT=gpurun_out/r02s; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?"; tail -5 $OUT/pytest.log
+timeout 900 bash scripts/ab.sh _base _ldsbar "" 2>&1 | tee $OUT/ab_resacc.txt

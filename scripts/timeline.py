@@ -12,7 +12,7 @@ from promonet_amd import _lib  # noqa: E402
 device = torch.device('cuda:0')
 lib = _lib.lib()
 for channels, length, k, d in ((256, 6888, 11, 5), (128, 55104, 11, 5),
-                               (128, 55104, 3, 1), (256, 6888, 3, 1)):
+                               (128, 55104, 7, 3), (128, 55104, 7, 1)):
     batch = 32
     x = torch.randn(batch, length, channels, device=device)
     out = torch.empty_like(x)
@@ -26,7 +26,7 @@ for channels, length, k, d in ((256, 6888, 11, 5), (128, 55104, 11, 5),
 
     def run():
         _lib.check(lib.pm_block_iteration_cl(
-            _lib.PM_F16, _lib.ptr(x), _lib.ptr(out), _lib.ptr(w1),
+            _lib.PM_BF16, _lib.ptr(x), _lib.ptr(out), _lib.ptr(w1),
             _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), batch, length, channels,
             k, d, 0, 1., ws.data_ptr(), ws.numel(), _lib.stream()))
 
@@ -51,7 +51,8 @@ for channels, length, k, d in ((256, 6888, 11, 5), (128, 55104, 11, 5),
     print('   stage %.0f | conv1 %.0f | epi1 %.0f | conv2 %.0f | epi2 %.0f' %
           tuple(phases.tolist()))
     if channels > 64:
-        e = t[:, [6, 7, 8, 9, 10, 11]] - t[:, [1, 6, 7, 8, 9, 10]]
-        print('   chunk0: mma %.0f store %.0f sync %.0f | chunk1: mma %.0f store %.0f sync %.0f' % tuple(e.mean(0).tolist()))
+        # stamps 6 / 8: end of chunk 0's MFMAs / after the barrier behind it
+        print('   conv1 chunk 0: mma %.0f, barrier %.0f' % (
+            (t[:, 6] - t[:, 1]).mean(), (t[:, 8] - t[:, 6]).mean()))
     print('   blocks/CU %.2f -> sum of block time per CU %.0f ticks' %
           (n / 256, n / 256 * total))
