@@ -13,6 +13,7 @@
 #define PM_LRELU_SLOPE 0.1f   // promonet/config/defaults.py:216
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int pm_u4 __attribute__((ext_vector_type(4)));   // buffer_load/store_b128
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -42,20 +42,30 @@ struct ChunkStager {
     float4 r[MAXIT];
 
     // Global (fp32, channels-last) -> registers. Rows outside [0, L) are the
-    // convolution's zero padding (true sequence ends only).
+    // convolution's zero padding (true sequence ends only): buffer loads
+    // over a descriptor of exactly the rows that exist, so a row outside
+    // reads as zero without a branch (its offset - negative rows wrap - is
+    // out of range). Unconditional loads also keep the compiler's vmcnt
+    // arithmetic exact: behind per-lane branches it cannot tell how many
+    // loads were issued and waits for (almost) everything in flight.
     __device__ __forceinline__ void load(
         const float* __restrict__ xb, int cstride, int c0, int t_first,
         int XR, int L, int tid) {
+        const int lo = max(t_first, 0);
+        const int hi = min(L, t_first + XR);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xb) + (size_t)lo * cstride, 0,
+            max(hi - lo, 0) * cstride * 4, 0x00020000);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int idx = tid + it * NT;
             const int row = idx / Q, q = idx % Q;
-            const int t = t_first + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < XR && t >= 0 && t < L)
-                v = *reinterpret_cast<const float4*>(
-                    xb + (size_t)t * cstride + c0 + q * 4);
-            r[it] = v;
+            const unsigned voff = (unsigned)(
+                ((t_first - lo + row) * cstride + c0 + q * 4) * 4);
+            const pm_u4 v =
+                __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+            r[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y),
+                                __uint_as_float(v.z), __uint_as_float(v.w));
         }
     }
 
@@ -179,16 +189,34 @@ __device__ __forceinline__ void mma_taps(
 // library carries none of it.
 #ifdef PM_TUNING
 #define PM_TIMELINE_FIELD unsigned long long* timeline;
-#define PM_STAMP(args, i)                                                    \
+#define PM_STAMP_AT(args, slot, i)                                           \
     do {                                                                     \
         if ((args).timeline && threadIdx.x == 0)                             \
-            (args).timeline[(size_t)blockIdx.x * 16 + (i)] =                  \
+            (args).timeline[(size_t)(slot) * 16 + (i)] =                      \
                 __builtin_amdgcn_s_memtime();                                \
+    } while (0)
+// constant 100 MHz clock + where the workgroup ran: shader clock rate and
+// the gap between consecutive tiles of a CU (scripts/timeline.py)
+#define PM_STAMP_WALL(args, slot, i)                                         \
+    do {                                                                     \
+        if ((args).timeline && threadIdx.x == 0)                             \
+            (args).timeline[(size_t)(slot) * 16 + (i)] = wall_clock64();      \
+    } while (0)
+#define PM_STAMP_PLACE(args, slot, i)                                        \
+    do {                                                                     \
+        if ((args).timeline && threadIdx.x == 0)                             \
+            (args).timeline[(size_t)(slot) * 16 + (i)] =                      \
+                ((unsigned long long)__builtin_amdgcn_s_getreg(              \
+                     (31 << 11) | 20) << 32) |                               \
+                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);         \
     } while (0)
 #else
 #define PM_TIMELINE_FIELD
-#define PM_STAMP(args, i) ((void)0)
+#define PM_STAMP_AT(args, slot, i) ((void)0)
+#define PM_STAMP_WALL(args, slot, i) ((void)0)
+#define PM_STAMP_PLACE(args, slot, i) ((void)0)
 #endif
+#define PM_STAMP(args, i) PM_STAMP_AT(args, blockIdx.x, i)
 
 // Bias step of a packed weight stream (see the layout comment above)
 template <class ET, int MTW>
@@ -321,9 +349,7 @@ __host__ __device__ constexpr int pair_smem_bytes(int d) {
 }
 
 template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS>
-__global__ __launch_bounds__(WM * WN * 64,
-                             WM * WN == 4 && ET::ESZ == 2 ? 2 : 1)
-void conv_pair_kernel(
+__global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     PairArgs a) {
     typedef typename ET::frag_t frag_t;
     constexpr int NCH = C / CH;
@@ -384,6 +410,8 @@ void conv_pair_kernel(
     frag_t bf[MTW];
     load_bias_frags<ET, MTW>(bf, w1 + W_BIAS, W_MT_STRIDE);
     PM_STAMP(a, 0);
+    PM_STAMP_WALL(a, blockIdx.x, 12);
+    PM_STAMP_PLACE(a, blockIdx.x, 14);
     const int lane_off_x =
         ((wn * NTW * 32) + ln) * SX + lh * 8 * ET::ESZ;
     frag_t afirst[G][MTW];
@@ -393,6 +421,11 @@ void conv_pair_kernel(
     ChunkStager<ET, CH, NT, XR_MAX> stager;
     stager.load(xb, C, 0, t_first, XR, L, tid);
     stager.template store<true>(xbuf, XR, tid);
+    // Chunk 1 is requested before the barrier, not behind it: vmcnt retires
+    // in order, so the weight groups the MFMA loop fetches queue up behind
+    // these loads - the earlier they go out, the shorter that first stall
+    // (timeline: chunk 0's MFMA phase took 13.9 k cycles, chunk 1's 9.0 k).
+    if (NCH > 1) stager.load(xb, C, CH, t_first, XR, L, tid);
     pm_block_sync();
     PM_STAMP(a, 1);
     bias_start<ET, MTW, NTW>(acc, bf);
@@ -401,7 +434,8 @@ void conv_pair_kernel(
     for (int c = 0; c < NCH; ++c) {
         char* cur = xbuf + (NCH > 1 ? (c & 1) * XR * SX : 0);
         const bool more = c + 1 < NCH;
-        if (more) stager.load(xb, C, (c + 1) * CH, t_first, XR, L, tid);
+        if (more && c > 0)
+            stager.load(xb, C, (c + 1) * CH, t_first, XR, L, tid);
         char* nxt = xbuf + ((c + 1) & 1) * XR * SX;
         auto stage_next = [&]() {
             if (more) stager.template store<true>(nxt, XR, tid);
@@ -438,7 +472,6 @@ void conv_pair_kernel(
             const int t_tile = t0 - H2 + n_first;
             store_tile_lrelu<ET>(inter + n * SI, (wm * MTW + mt) * 32,
                                  acc[mt][nt], t_tile, L, ln, lh);
-#ifndef PM_EXP_NO_RESACC
             // (columns beyond the tile / the utterance are never stored:
             // they load a valid row and their sums are don't-cares)
             const int t = min(t0 + n, L - 1);
@@ -452,17 +485,11 @@ void conv_pair_kernel(
                 acc[mt][nt][4 * g4 + 2] = r.z;
                 acc[mt][nt][4 * g4 + 3] = r.w;
             }
-#endif
         }
     }
-#ifdef PM_EXP_NO_RESACC
-    bias_start<ET, MTW, NTW>(acc, bf);
-    pm_block_sync();
-#else
     pm_block_sync();
     __builtin_amdgcn_sched_barrier(0);   // the bias MFMAs wait for the loads:
     bias_add<ET, MTW, NTW>(acc, bf);     // keep them behind the barrier
-#endif
     PM_STAMP(a, 3);
 
     // ---------------- conv2 (dilation 1) straight out of LDS ---------------
@@ -480,47 +507,56 @@ void conv_pair_kernel(
     // All global loads of a 32x32 tile are issued before its first store:
     // interleaved, every load queued behind the previous store's address
     // dependence and the epilogue became 16 serial HBM round trips.
-    float* __restrict__ ob = a.out + (size_t)b * a.L * C;
+    // Buffer accesses: rows beyond the tile / the utterance fall outside
+    // the descriptor's range - stores are dropped, loads return 0 - so the
+    // epilogue has no per-lane branches.
     const int mode = a.mode;
     const float scale = a.scale;
-#ifndef PM_EXP_NO_RESACC
+    const int rows = min(TL, L - t0);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out + ((size_t)b * a.L + t0) * C, 0, rows * C * 4, 0x00020000);
+    const unsigned voff0 =
+        (unsigned)(((wn * NTW * 32 + ln) * C + wm * MTW * 32 + 4 * lh) * 4);
     if (mode == 2) {
-        // MRF accumulation: every read of `out` is issued before the first
-        // store (one round trip for the whole wave tile; the operand
-        // fragment registers are dead by now)
-        float4 old[MTW][NTW][4];
+        // MRF accumulation: the reads of `out` are issued in batches before
+        // the first store of a batch (one round trip per batch, not per
+        // tile; the operand fragment registers are dead by now)
+        constexpr int NB = NTW > 4 ? (NTW + 1) / 2 : NTW;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                const int n = (wn * NTW + nt) * 32 + ln;
-                const int t = t0 + n;
-                const bool live = n < TL && t < L;
-                const float* orow = ob + (size_t)(live ? t : 0) * C +
-                                    (wm * MTW + mt) * 32 + 4 * lh;
+            for (int n0 = 0; n0 < NTW; n0 += NB) {
+                pm_u4 old[NB][4];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    old[mt][nt][g4] =
-                        *reinterpret_cast<const float4*>(orow + 8 * g4);
-            }
+                for (int i = 0; i < NB; ++i) {
+                    if (n0 + i >= NTW) break;
+                    const unsigned voff =
+                        voff0 + (unsigned)((mt * 32 + (n0 + i) * 32 * C) * 4);
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        old[i][g4] = __builtin_amdgcn_raw_buffer_load_b128(
+                            orsrc, voff + g4 * 32, 0, 0);
+                }
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                const int n = (wn * NTW + nt) * 32 + ln;
-                const int t = t0 + n;
-                if (n < TL && t < L) {
-                    float* orow = ob + (size_t)t * C +
-                                  (wm * MTW + mt) * 32 + 4 * lh;
+                for (int i = 0; i < NB; ++i) {
+                    if (n0 + i >= NTW) break;
+                    const int nt = n0 + i;
+                    const unsigned voff =
+                        voff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const float4 o = old[mt][nt][g4];
-                        float4 v;
-                        v.x = o.x + acc[mt][nt][4 * g4 + 0] * scale;
-                        v.y = o.y + acc[mt][nt][4 * g4 + 1] * scale;
-                        v.z = o.z + acc[mt][nt][4 * g4 + 2] * scale;
-                        v.w = o.w + acc[mt][nt][4 * g4 + 3] * scale;
-                        *reinterpret_cast<float4*>(orow + 8 * g4) = v;
+                        const pm_u4 o = old[i][g4];
+                        pm_u4 r;
+                        r.x = __float_as_uint(__uint_as_float(o.x) +
+                                              acc[mt][nt][4 * g4 + 0] * scale);
+                        r.y = __float_as_uint(__uint_as_float(o.y) +
+                                              acc[mt][nt][4 * g4 + 1] * scale);
+                        r.z = __float_as_uint(__uint_as_float(o.z) +
+                                              acc[mt][nt][4 * g4 + 2] * scale);
+                        r.w = __float_as_uint(__uint_as_float(o.w) +
+                                              acc[mt][nt][4 * g4 + 3] * scale);
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            r, orsrc, voff + g4 * 32, 0, 0);
                     }
                 }
             }
@@ -530,63 +566,22 @@ void conv_pair_kernel(
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                const int n = (wn * NTW + nt) * 32 + ln;
-                const int t = t0 + n;
-                if (n < TL && t < L) {
-                    float* orow = ob + (size_t)t * C +
-                                  (wm * MTW + mt) * 32 + 4 * lh;
+                const unsigned voff =
+                    voff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4)
-                        *reinterpret_cast<float4*>(orow + 8 * g4) =
-                            make_float4(acc[mt][nt][4 * g4 + 0] * s,
-                                        acc[mt][nt][4 * g4 + 1] * s,
-                                        acc[mt][nt][4 * g4 + 2] * s,
-                                        acc[mt][nt][4 * g4 + 3] * s);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    pm_u4 r;
+                    r.x = __float_as_uint(acc[mt][nt][4 * g4 + 0] * s);
+                    r.y = __float_as_uint(acc[mt][nt][4 * g4 + 1] * s);
+                    r.z = __float_as_uint(acc[mt][nt][4 * g4 + 2] * s);
+                    r.w = __float_as_uint(acc[mt][nt][4 * g4 + 3] * s);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        r, orsrc, voff + g4 * 32, 0, 0);
                 }
             }
     }
-#else
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-        const int co_base = (wm * MTW + mt) * 32 + 4 * lh;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int n = (wn * NTW + nt) * 32 + ln;
-            const int t = t0 + n;
-            if (n < TL && t < L) {
-                float4 res[4], old[4];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int co = co_base + 8 * g4;
-                    res[g4] = *reinterpret_cast<const float4*>(
-                        xb + (size_t)t * C + co);
-                    if (mode == 2)
-                        old[g4] = *reinterpret_cast<const float4*>(
-                            ob + (size_t)t * C + co);
-                }
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int co = co_base + 8 * g4;
-                    float4 v;
-                    v.x = acc[mt][nt][4 * g4 + 0] + res[g4].x;
-                    v.y = acc[mt][nt][4 * g4 + 1] + res[g4].y;
-                    v.z = acc[mt][nt][4 * g4 + 2] + res[g4].z;
-                    v.w = acc[mt][nt][4 * g4 + 3] + res[g4].w;
-                    if (mode == 1) {
-                        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-                    } else if (mode == 2) {
-                        v.x = old[g4].x + v.x * scale;
-                        v.y = old[g4].y + v.y * scale;
-                        v.z = old[g4].z + v.z * scale;
-                        v.w = old[g4].w + v.w * scale;
-                    }
-                    *reinterpret_cast<float4*>(ob + (size_t)t * C + co) = v;
-                }
-            }
-        }
-    }
-#endif
     PM_STAMP(a, 5);
+    PM_STAMP_WALL(a, blockIdx.x, 13);
 }
 
 // ---------------------------------------------------------------------------

@@ -91,11 +91,7 @@ template <> struct PairCfg<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 6, CH = 
 // fed by LDS-DMA from a 16-bit copy of lrelu(x) (no staging registers, no
 // spills) is still 3-6 % slower, 8 waves on 512 columns 7-13 % slower
 // (profiles/r02/ab_pair_dma_*.txt).
-#ifdef PM_EXP_PAIR128_2WG
-template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 1, NTW = 6, CH = 32, ALIAS = 1 }; };
-#else
 template <> struct PairCfg<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 4, CH = 64, ALIAS = 0 }; };
-#endif
 template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2, CH = 64, ALIAS = 0 }; };
 template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
 template <int C> struct PairCfg<ElemBF16, C> : PairCfg<ElemF16, C> {};
@@ -113,11 +109,7 @@ template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 
 template <class ET, int C> struct PairCfgNarrow : PairCfg<ET, C> {};
 // (CH must equal the wide variant's: both read the same packed weights)
 template <> struct PairCfgNarrow<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 2, CH = PairCfg<ElemF16, 256>::CH, ALIAS = 1 }; };
-#ifdef PM_EXP_PAIR128_2WG
-template <> struct PairCfgNarrow<ElemF16, 128> { enum { WM = 4, WN = 1, NTW = 4, CH = PairCfg<ElemF16, 128>::CH, ALIAS = 1 }; };
-#else
 template <> struct PairCfgNarrow<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2, CH = PairCfg<ElemF16, 128>::CH, ALIAS = 0 }; };
-#endif
 template <> struct PairCfgNarrow<ElemBF16, 256> : PairCfgNarrow<ElemF16, 256> {};
 template <> struct PairCfgNarrow<ElemBF16, 128> : PairCfgNarrow<ElemF16, 128> {};
 #define PM_NARROW_BELOW 150   // 3x the tiles must still fit ~2 rounds of 256 CUs

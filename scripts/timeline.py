@@ -54,5 +54,32 @@ for channels, length, k, d in ((256, 6888, 11, 5), (128, 55104, 11, 5),
         # stamps 6 / 8: end of chunk 0's MFMAs / after the barrier behind it
         print('   conv1 chunk 0: mma %.0f, barrier %.0f' % (
             (t[:, 6] - t[:, 1]).mean(), (t[:, 8] - t[:, 6]).mean()))
+    # shader clock against the constant 100 MHz clock; idle gap between
+    # consecutive workgroups of one CU (the place = XCC id, HW_ID[15:8])
+    wall = (t[:, 13] - t[:, 12]) * 10.          # ns
+    ghz = ((t[:, 5] - t[:, 0]) / wall).mean()
+    raw = stamps.cpu()[used.nonzero().squeeze(1)]
+    place = ((raw[:, 14] >> 32) << 8) | ((raw[:, 14] >> 8) & 0xff)
+    gaps, busy = [], []
+    for cu in place.unique().tolist():
+        rows = raw[place == cu]
+        rows = rows[rows[:, 12].argsort()]
+        gaps.append(((rows[1:, 12] - rows[:-1, 13]).double() * 10.))
+        busy.append(((rows[:, 13] - rows[:, 12]).double().sum() * 10.) /
+                    ((rows[-1, 13] - rows[0, 12]).double() * 10.))
+    # lockstep check: spread over the CUs of the start time of a CU's k-th tile
+    kth = {}
+    for cu in place.unique().tolist():
+        rows = raw[place == cu]
+        starts = rows[:, 12].sort().values
+        for k in (1, 5, 10, 20):
+            if k < starts.numel():
+                kth.setdefault(k, []).append(starts[k].item())
+    spread = ' '.join('k=%d: %.1f us' % (k, torch.tensor(v).double().std() * 1e-2)
+                      for k, v in sorted(kth.items()))
+    print('   std over CUs of the start of a CU\'s k-th tile: ' + spread)
+    gaps = torch.cat(gaps)
+    print('   shader clock %.2f GHz | %d CUs seen | gap between workgroups of a CU: mean %.0f ns, median %.0f ns | CU occupied %.1f %% of its span' % (
+        ghz, place.unique().numel(), gaps.mean(), gaps.median(), 100 * torch.tensor(busy).mean()))
     print('   blocks/CU %.2f -> sum of block time per CU %.0f ticks' %
           (n / 256, n / 256 * total))
