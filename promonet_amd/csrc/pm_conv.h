@@ -378,6 +378,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     const int wm = wave / WN, wn = wave % WN;
     const int ln = lane & 31, lh = lane >> 5;
 
+    // The second-dispatched half of an 8-wave workgroup loses every issue
+    // arbitration to its older SIMD partner; a static priority evens the
+    // pair out (-0.3 % of the step, profiles/r02/ab_block_buffer_ops_prio.txt)
+    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int wg = pm_xcd_remap(blockIdx.x, gridDim.x);
     const int tile = wg % a.ntiles;
     const int b = wg / a.ntiles;
@@ -877,6 +881,7 @@ __device__ __forceinline__ void block3_body(
     const int wm = wave / WN, wn = wave % WN;
     const int m_first = wm * MTW * 32;     // this wave's first channel
     const int ln = lane & 31, lh = lane >> 5;
+    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);   // see the pair kernel
 
     const int wg = pm_xcd_remap(blockIdx.x, gridDim.x);
     const int tile = wg % a.ntiles;
@@ -907,25 +912,34 @@ __device__ __forceinline__ void block3_body(
     // utterance), and a = lrelu(x) -> LDS out of the same registers: the
     // workgroup's NC columns are exactly its waves' tiles, so x is read from
     // HBM once. All loads are issued before the first LDS write.
+    // (buffer loads over a descriptor of exactly the rows of the utterance
+    // this tile covers: a column outside reads as zero without a branch)
     floatx16 trunk[MTW][NTW];
+    {
+        const int lo = max(c_first, 0);
+        const int hi = min(L, c_first + NC);
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xb) + (size_t)lo * C, 0,
+            max(hi - lo, 0) * C * 4, 0x00020000);
+        const unsigned voff0 = (unsigned)(
+            ((c_first - lo + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int t = c_first + (wn * NTW + nt) * 32 + ln;
-            const bool inside = t >= 0 && t < L;
+            for (int nt = 0; nt < NTW; ++nt) {
+                const unsigned voff =
+                    voff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (inside)
-                    v = *reinterpret_cast<const float4*>(
-                        xb + (size_t)t * C + m_first + mt * 32 + 8 * g4 + 4 * lh);
-                trunk[mt][nt][4 * g4 + 0] = v.x;
-                trunk[mt][nt][4 * g4 + 1] = v.y;
-                trunk[mt][nt][4 * g4 + 2] = v.z;
-                trunk[mt][nt][4 * g4 + 3] = v.w;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const pm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                        xrsrc, voff + g4 * 32, 0, 0);
+                    trunk[mt][nt][4 * g4 + 0] = __uint_as_float(v.x);
+                    trunk[mt][nt][4 * g4 + 1] = __uint_as_float(v.y);
+                    trunk[mt][nt][4 * g4 + 2] = __uint_as_float(v.z);
+                    trunk[mt][nt][4 * g4 + 3] = __uint_as_float(v.w);
+                }
             }
-        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -1035,45 +1049,79 @@ __device__ __forceinline__ void block3_body(
             for (int nt = 0; nt < NTW; ++nt) trunk[mt][nt] += sum[mt][nt];
     }
     // ---- store the valid interior (+ MRF accumulate) ----------------------
-    float* __restrict__ ob = a.out + (size_t)b * a.L * C;
+    // Buffer accesses over a descriptor of exactly the rows this tile owns:
+    // halo columns and columns beyond the utterance are out of range (stores
+    // dropped, loads 0) - no per-lane branches.
     const int mode = SUM == 3 ? 1 : a.mode;
     const float scale = a.scale;
+    const int own_first = tile * a.TL;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out + ((size_t)b * a.L + own_first) * C, 0,
+        min(a.TL, L - own_first) * C * 4, 0x00020000);
+    const unsigned ovoff0 = (unsigned)(
+        ((wn * NTW * 32 + ln - a.halo) * C + m_first + 4 * lh) * 4);
+    if (mode == 2) {
+        // the reads of `out` go out in batches before the first store of a
+        // batch: one round trip per batch, not per 32 x 32 tile
+        constexpr int NB = NTW > 4 ? (NTW + 1) / 2 : NTW;
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int col = (wn * NTW + nt) * 32 + ln;
-            const int t = c_first + col;
-            if (col >= a.halo && col < a.halo + a.TL && t < L) {
-                float4 old[4];
-                if (mode == 2) {
+            for (int n0 = 0; n0 < NTW; n0 += NB) {
+                pm_u4 old[NB][4];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (n0 + i >= NTW) break;
+                    const unsigned voff = ovoff0 +
+                        (unsigned)((mt * 32 + (n0 + i) * 32 * C) * 4);
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4)
-                        old[g4] = *reinterpret_cast<const float4*>(
-                            ob + (size_t)t * C + m_first + mt * 32 + 8 * g4 +
-                            4 * lh);
+                        old[i][g4] = __builtin_amdgcn_raw_buffer_load_b128(
+                            orsrc, voff + g4 * 32, 0, 0);
                 }
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int co = m_first + mt * 32 + 8 * g4 + 4 * lh;
-                    float4 v;
-                    v.x = trunk[mt][nt][4 * g4 + 0];
-                    v.y = trunk[mt][nt][4 * g4 + 1];
-                    v.z = trunk[mt][nt][4 * g4 + 2];
-                    v.w = trunk[mt][nt][4 * g4 + 3];
-                    if (mode == 1) {
-                        v.x *= scale; v.y *= scale;
-                        v.z *= scale; v.w *= scale;
-                    } else if (mode == 2) {
-                        v.x = old[g4].x + v.x * scale;
-                        v.y = old[g4].y + v.y * scale;
-                        v.z = old[g4].z + v.z * scale;
-                        v.w = old[g4].w + v.w * scale;
+                for (int i = 0; i < NB; ++i) {
+                    if (n0 + i >= NTW) break;
+                    const int nt = n0 + i;
+                    const unsigned voff =
+                        ovoff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const pm_u4 o = old[i][g4];
+                        pm_u4 r;
+                        r.x = __float_as_uint(__uint_as_float(o.x) +
+                                              trunk[mt][nt][4 * g4 + 0] * scale);
+                        r.y = __float_as_uint(__uint_as_float(o.y) +
+                                              trunk[mt][nt][4 * g4 + 1] * scale);
+                        r.z = __float_as_uint(__uint_as_float(o.z) +
+                                              trunk[mt][nt][4 * g4 + 2] * scale);
+                        r.w = __float_as_uint(__uint_as_float(o.w) +
+                                              trunk[mt][nt][4 * g4 + 3] * scale);
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            r, orsrc, voff + g4 * 32, 0, 0);
                     }
-                    *reinterpret_cast<float4*>(ob + (size_t)t * C + co) = v;
                 }
             }
-        }
+    } else {
+        const float sc = mode == 1 ? scale : 1.f;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const unsigned voff =
+                    ovoff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    pm_u4 r;
+                    r.x = __float_as_uint(trunk[mt][nt][4 * g4 + 0] * sc);
+                    r.y = __float_as_uint(trunk[mt][nt][4 * g4 + 1] * sc);
+                    r.z = __float_as_uint(trunk[mt][nt][4 * g4 + 2] * sc);
+                    r.w = __float_as_uint(trunk[mt][nt][4 * g4 + 3] * sc);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        r, orsrc, voff + g4 * 32, 0, 0);
+                }
+            }
+    }
     PM_STAMP(a, 14);
 }
 
