@@ -146,13 +146,9 @@ struct ElemF32 {
 // land before the wave may even ARRIVE. Fencing the LDS alone keeps those
 // loads in flight across the barrier.
 __device__ __forceinline__ void pm_block_sync() {
-#ifdef PM_EXP_NO_LDSBAR
-    __syncthreads();
-#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-#endif
 }
 
 // Bijective XCD-aware remap of a linear workgroup id: the dispatcher places

@@ -851,10 +851,18 @@ __host__ __device__ constexpr int block3_smem_bytes() {
 // SUM: 0 = stand-alone Block (store per a.mode); inside a whole-MRF launch
 // with the sum of the Blocks held in registers: 1 = first Block (sum = y),
 // 2 = middle (sum += y), 3 = last (store (sum + y) * scale).
-template <class ET, int C, int K, int WM, int WN, int NTW, int SUM = 0>
+// XMODE (whole-MRF launches, where the three Blocks start from the same x
+// tile): bit 0 = start from `xnext` instead of reading x from memory; bit 1 =
+// request x again for the NEXT Block during the last iteration's epilogue 1,
+// into the conv1 accumulators (dead from there on), and hand it over in
+// `xnext`: the round trip runs under the last conv2 instead of in front of
+// the next Block's first conv.
+template <class ET, int C, int K, int WM, int WN, int NTW, int SUM = 0,
+          int XMODE = 0>
 __device__ __forceinline__ void block3_body(
     const Block3Args& a, char* smem,
-    floatx16 (&sum)[(C / 32) / WM][NTW]) {
+    floatx16 (&sum)[(C / 32) / WM][NTW],
+    floatx16 (&xnext)[(C / 32) / WM][NTW]) {
     typedef typename ET::frag_t frag_t;
     constexpr int CH = C < 64 ? C : 64;    // weight-stream chunk (as packed)
     constexpr int NCH = C / CH;
@@ -915,14 +923,19 @@ __device__ __forceinline__ void block3_body(
     // (buffer loads over a descriptor of exactly the rows of the utterance
     // this tile covers: a column outside reads as zero without a branch)
     floatx16 trunk[MTW][NTW];
-    {
-        const int lo = max(c_first, 0);
-        const int hi = min(L, c_first + NC);
-        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(xb) + (size_t)lo * C, 0,
-            max(hi - lo, 0) * C * 4, 0x00020000);
-        const unsigned voff0 = (unsigned)(
-            ((c_first - lo + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
+    const int x_lo = max(c_first, 0);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(xb) + (size_t)x_lo * C, 0,
+        max(min(L, c_first + NC) - x_lo, 0) * C * 4, 0x00020000);
+    const unsigned xvoff0 = (unsigned)(
+        ((c_first - x_lo + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
+    if constexpr (XMODE & 1) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) trunk[mt][nt] = xnext[mt][nt];
+    } else {
+        const unsigned voff0 = xvoff0;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -990,6 +1003,22 @@ __device__ __forceinline__ void block3_body(
                 const int t_tile = c_first + col_first;
                 store_tile_lrelu<ET>(tbuf + (H2 + col) * S, m_first + mt * 32,
                                      acc[mt][nt], t_tile, L, ln, lh);
+                if constexpr (XMODE & 2) {
+                    if (it + 1 == a.niter) {
+                        const unsigned voff =
+                            xvoff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const pm_u4 v =
+                                __builtin_amdgcn_raw_buffer_load_b128(
+                                    xrsrc, voff + g4 * 32, 0, 0);
+                            acc[mt][nt][4 * g4 + 0] = __uint_as_float(v.x);
+                            acc[mt][nt][4 * g4 + 1] = __uint_as_float(v.y);
+                            acc[mt][nt][4 * g4 + 2] = __uint_as_float(v.z);
+                            acc[mt][nt][4 * g4 + 3] = __uint_as_float(v.w);
+                        }
+                    }
+                }
             }
         // ---- conv2 (dilation 1) out of `t`, accumulated IN PLACE onto the
         // fp32 trunk (the residual add is the MFMA's C operand) ----
@@ -1032,6 +1061,12 @@ __device__ __forceinline__ void block3_body(
         PM_STAMP(a, 5 + 4 * it);
     }
 
+    if constexpr (XMODE & 2) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) xnext[mt][nt] = acc[mt][nt];
+    }
     if constexpr (SUM == 1 || SUM == 2) {
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
@@ -1135,7 +1170,7 @@ __global__ __launch_bounds__(WM * WN * 64,
 void conv_block3_kernel(Block3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     floatx16 unused[(C / 32) / WM][NTW];
-    block3_body<ET, C, K, WM, WN, NTW>(a, smem, unused);
+    block3_body<ET, C, K, WM, WN, NTW>(a, smem, unused, unused);
 }
 
 // Whole MRF stage (the three Blocks k = 3, 7, 11 of one upsampling stage,
@@ -1155,16 +1190,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_kernel(MrfArgs m) {
         // the sum of the Blocks stays in registers (no read-modify-write of
         // `out`); k = 11 first: its MFMA loop has the highest register
         // pressure and runs before the sum is live
-        block3_body<ET, C, 11, WM, WN, NTW, 1>(m.k[2], smem, sum);
+        // (the three Blocks start from the same x tile - the launcher checks
+        // - and each requests it for the next one under its last conv2)
+        floatx16 xnext[(C / 32) / WM][NTW];
+        block3_body<ET, C, 11, WM, WN, NTW, 1, 2>(m.k[2], smem, sum, xnext);
         pm_block_sync();
-        block3_body<ET, C, 7, WM, WN, NTW, 2>(m.k[1], smem, sum);
+        block3_body<ET, C, 7, WM, WN, NTW, 2, 3>(m.k[1], smem, sum, xnext);
         pm_block_sync();
-        block3_body<ET, C, 3, WM, WN, NTW, 3>(m.k[0], smem, sum);
+        block3_body<ET, C, 3, WM, WN, NTW, 3, 1>(m.k[0], smem, sum, xnext);
     } else {
-        block3_body<ET, C, 3, WM, WN, NTW>(m.k[0], smem, sum);
+        block3_body<ET, C, 3, WM, WN, NTW>(m.k[0], smem, sum, sum);
         pm_block_sync();
-        block3_body<ET, C, 7, WM, WN, NTW>(m.k[1], smem, sum);
+        block3_body<ET, C, 7, WM, WN, NTW>(m.k[1], smem, sum, sum);
         pm_block_sync();
-        block3_body<ET, C, 11, WM, WN, NTW>(m.k[2], smem, sum);
+        block3_body<ET, C, 11, WM, WN, NTW>(m.k[2], smem, sum, sum);
     }
 }

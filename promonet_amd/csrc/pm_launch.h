@@ -296,6 +296,11 @@ static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stre
     }
     const int TL = NC - 2 * halo;
     if (TL < 32) return hipErrorNotSupported;
+    // one x tile serves the three Blocks (generator.py MRF: every Block of a
+    // stage reads the stage input)
+    if (blocks[0].x != blocks[1].x || blocks[0].x != blocks[2].x ||
+        blocks[0].L != blocks[1].L || blocks[0].L != blocks[2].L)
+        return hipErrorNotSupported;
     for (int j = 0; j < 3; ++j) {
         m.k[j].halo = halo; m.k[j].TL = TL;
         m.k[j].ntiles = (m.k[j].L + TL - 1) / TL;
