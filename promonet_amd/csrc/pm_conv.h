@@ -708,35 +708,41 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
     }
 
     if constexpr (EPI == 0) {
-    float* ob = a.out + (size_t)b * a.Lout * M;
+    // buffer stores over the rows of this utterance the tile owns: columns
+    // beyond Lout are out of range and dropped (no per-lane branch); the
+    // bias of an M tile is read once, not once per column tile
     const float* gb = a.gbias
         ? a.gbias + (size_t)(a.gbias_batch == 1 ? 0 : b) * M : nullptr;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out + ((size_t)b * a.Lout + t0) * M, 0,
+        min(Lout - t0, N1) * M * 4, 0x00020000);
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         const int co_base = m0 + mt * 32 + 4 * lh;
+        float4 bias[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = co_base + 8 * g4;
+            bias[g4] = *reinterpret_cast<const float4*>(a.bias + co);
+            if (gb) {
+                const float4 g = *reinterpret_cast<const float4*>(gb + co);
+                bias[g4].x += g.x; bias[g4].y += g.y;
+                bias[g4].z += g.z; bias[g4].w += g.w;
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int n = (wn * NTW + nt) * 32 + ln;
-            const int t = t0 + n;
-            if (t < Lout) {
+            const unsigned voff = (unsigned)((n * M + co_base) * 4);
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int co = co_base + 8 * g4;
-                    float4 bias =
-                        *reinterpret_cast<const float4*>(a.bias + co);
-                    if (gb) {
-                        const float4 g =
-                            *reinterpret_cast<const float4*>(gb + co);
-                        bias.x += g.x; bias.y += g.y;
-                        bias.z += g.z; bias.w += g.w;
-                    }
-                    float4 v;
-                    v.x = acc[mt][nt][4 * g4 + 0] + bias.x;
-                    v.y = acc[mt][nt][4 * g4 + 1] + bias.y;
-                    v.z = acc[mt][nt][4 * g4 + 2] + bias.z;
-                    v.w = acc[mt][nt][4 * g4 + 3] + bias.w;
-                    *reinterpret_cast<float4*>(ob + (size_t)t * M + co) = v;
-                }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                pm_u4 r;
+                r.x = __float_as_uint(acc[mt][nt][4 * g4 + 0] + bias[g4].x);
+                r.y = __float_as_uint(acc[mt][nt][4 * g4 + 1] + bias[g4].y);
+                r.z = __float_as_uint(acc[mt][nt][4 * g4 + 2] + bias[g4].z);
+                r.w = __float_as_uint(acc[mt][nt][4 * g4 + 3] + bias[g4].w);
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    r, orsrc, voff + g4 * 32, 0, 0);
             }
         }
     }
