@@ -225,6 +225,16 @@ static hipError_t pad_bias(
     return hipGetLastError();
 }
 
+// Wide upsampler (conv_upsample_kernel): 16-bit operands, C_in 256 / 512,
+// 256-row M blocks whose tap window is uniform. Sets the single-chunk packing.
+static bool upsample_whole_k(int dtype, ConvGeom& g) {
+    if (dtype == PM_F32 || g.mode != 1) return false;
+    if (g.cin_pad != 256 && g.cin_pad != 512) return false;
+    if (g.M % 256 || ((g.r / 2) * g.cout_pad) % 64) return false;
+    g.ch = g.cin_pad;
+    return true;
+}
+
 static int single_cfg(int M, int ch, int wave64_ok) {
     if (M % 256 == 0 && ch == 64 && wave64_ok) return 0;
     if (M == 128 && ch == 64) return 3;   // whole M in one workgroup
@@ -368,8 +378,9 @@ extern "C" int pm_hifigan_create(
         g.cout_pad = s.cout_pad; g.cin_pad = s.cin_pad;
         g.M = s.r * s.cout_pad; g.kt = 2; g.r = s.r; g.p = s.r / 2;
         g.ch = (s.cin_pad % 64 == 0) ? 64 : 32;
-        s.up.cfg = single_cfg(
-            g.M, g.ch, ((s.r / 2) * s.cout_pad) % 64 == 0);
+        s.up.cfg = upsample_whole_k(h->dtype, g)
+            ? 4
+            : single_cfg(g.M, g.ch, ((s.r / 2) * s.cout_pad) % 64 == 0);
         for (int j = 0; j < c->num_resblocks; ++j)
             for (int n = 0; n < c->num_dilations; ++n)
                 for (int which = 0; which < 2; ++which) {
@@ -1188,7 +1199,9 @@ extern "C" int pm_conv_transpose_cl(
     g.cout_pad = pad32(c_out); g.cin_pad = pad32(c_in);
     g.M = r * g.cout_pad; g.kt = 2; g.r = r; g.p = r / 2;
     g.ch = (g.cin_pad % 64 == 0) ? 64 : 32;
-    const int cfg = single_cfg(g.M, g.ch, ((r / 2) * g.cout_pad) % 64 == 0);
+    const int cfg = upsample_whole_k(dtype, g)
+        ? 4
+        : single_cfg(g.M, g.ch, ((r / 2) * g.cout_pad) % 64 == 0);
     char* base = (char*)ws;
     const size_t wsz = 2 * align256((size_t)g.cin_pad * g.cout_pad * g.k * 4);
     float* pb = (float*)(base + wsz);

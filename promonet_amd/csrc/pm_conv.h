@@ -70,14 +70,15 @@ struct ChunkStager {
     }
 
     // Registers -> LDS with the input activation and operand conversion fused
-    template <bool LRELU>
+    // (STRIDE: LDS row pitch, when the chunk is a slab of a wider tile)
+    template <bool LRELU, int STRIDE = S>
     __device__ __forceinline__ void store(char* buf, int XR, int tid) {
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int idx = tid + it * NT;
             const int row = idx / Q, q = idx % Q;
             if (row < XR) {
-                ET::store4(buf + row * S + q * 4 * ET::ESZ,
+                ET::store4(buf + row * STRIDE + q * 4 * ET::ESZ,
                            LRELU ? pm_lrelu4(r[it]) : r[it]);
             }
         }
@@ -818,6 +819,131 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
         if (lane == 0 && local_max > -INFINITY)
             atomicMax(a.maxbits + b, pm_float_order_bits(local_max));
     }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Wide polyphase upsampler (C_in = 256 / 512, r = 8: M = r C_out = 1024 / 2048
+// GEMM rows, K = 2 C_in): conv_single_kernel walks K in 64-channel chunks and
+// covers M with one workgroup per 256 rows, so the same x tile is staged
+// M / 256 times and an MFMA phase between two barriers is 8 k16-steps long.
+// Here the whole x tile ((128 + 2) rows x C_in, 16-bit) is staged ONCE and the
+// workgroup walks its M blocks with no barrier in between - one continuous
+// weight stream (packed as a single chunk, CH = C_in).
+// ---------------------------------------------------------------------------
+template <class ET, int CIN, int WM, int WN, int MTW, int NTW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_upsample_kernel(
+    SingleArgs a) {
+    typedef typename ET::frag_t frag_t;
+    constexpr int KT = 2, KSPAN = 3;
+    constexpr int KC = CIN / 16;
+    constexpr int N1 = WN * NTW * 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int S = CIN * ET::ESZ + 16;
+    constexpr int XR = N1 + KSPAN - 1;
+    constexpr int MB = WM * MTW * 32;
+    // (depth 2 under a 128-register cap, so that two workgroups share a CU
+    // at C_in = 256, is 12 % slower: profiles/r02/ab_upsample_whole_k.txt)
+    constexpr int G = 4;
+    constexpr int SLAB = 128;          // channels staged per register pass
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ln = lane & 31, lh = lane >> 5;
+
+    // nmblocks = M groups per column tile (adjacent workgroup ids: the groups
+    // of a tile share its x rows in one XCD's L2)
+    const int wg = pm_xcd_remap(blockIdx.x, gridDim.x);
+    const int mg = wg % a.nmblocks;
+    const int tile = (wg / a.nmblocks) % a.ntiles;
+    const int b = wg / (a.nmblocks * a.ntiles);
+    const int t0 = tile * N1;
+    const int M = a.M;
+    const int L = a.lengths ? min(a.lengths[b] * a.len_scale, a.L) : a.L;
+    const int Lout = a.lengths ? L : a.Lout;
+    if (t0 >= Lout) return;
+
+    const float* xb = a.x + (size_t)b * a.L * CIN;
+    const int t_first = t0 - a.pad;
+    {
+        ChunkStager<ET, SLAB, NT, XR> stager;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CIN; c0 += SLAB) {
+            stager.load(xb, CIN, c0, t_first, XR, L, tid);
+            if (a.lrelu)
+                stager.template store<true, S>(smem + c0 * ET::ESZ, XR, tid);
+            else
+                stager.template store<false, S>(smem + c0 * ET::ESZ, XR, tid);
+        }
+    }
+    pm_block_sync();
+
+    constexpr int w_mt_stride = KT * KC * 64;
+    const int per_group = (M / MB) / a.nmblocks;
+    const frag_t* wbase = reinterpret_cast<const frag_t*>(a.w) + lane;
+    const float* gb = a.gbias
+        ? a.gbias + (size_t)(a.gbias_batch == 1 ? 0 : b) * M : nullptr;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out + ((size_t)b * a.Lout + t0) * M, 0,
+        min(Lout - t0, N1) * M * 4, 0x00020000);
+
+    frag_t afirst[G][MTW];
+    load_a_group<ET, MTW, G>(
+        afirst,
+        wbase + (size_t)((mg * per_group * MB + wm * MTW * 32) / 32) * w_mt_stride,
+        w_mt_stride);
+#pragma unroll 1
+    for (int mi = 0; mi < per_group; ++mi) {
+        const int m0 = (mg * per_group + mi) * MB + wm * MTW * 32;
+        const int js =
+            (a.phase_r > 0 && (m0 / a.phase_c) + a.phase_p >= a.phase_r) ? 1 : 0;
+        const frag_t* w = wbase + (size_t)(m0 / 32) * w_mt_stride;
+        floatx16 acc[MTW][NTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        const int lane_off =
+            ((wn * NTW * 32) + ln + js) * S + lh * 8 * ET::ESZ;
+        mma_taps<ET, KT, KC, MTW, NTW, G, S>(
+            acc, smem + lane_off, S, w, w_mt_stride, afirst,
+            mi + 1 < per_group ? w + (size_t)(MB / 32) * w_mt_stride : nullptr);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int co_base = m0 + mt * 32 + 4 * lh;
+            float4 bias[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int co = co_base + 8 * g4;
+                bias[g4] = *reinterpret_cast<const float4*>(a.bias + co);
+                if (gb) {
+                    const float4 g = *reinterpret_cast<const float4*>(gb + co);
+                    bias[g4].x += g.x; bias[g4].y += g.y;
+                    bias[g4].z += g.z; bias[g4].w += g.w;
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = (wn * NTW + nt) * 32 + ln;
+                const unsigned voff = (unsigned)((n * M + co_base) * 4);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    pm_u4 r;
+                    r.x = __float_as_uint(acc[mt][nt][4 * g4 + 0] + bias[g4].x);
+                    r.y = __float_as_uint(acc[mt][nt][4 * g4 + 1] + bias[g4].y);
+                    r.z = __float_as_uint(acc[mt][nt][4 * g4 + 2] + bias[g4].z);
+                    r.w = __float_as_uint(acc[mt][nt][4 * g4 + 3] + bias[g4].w);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        r, orsrc, voff + g4 * 32, 0, 0);
+                }
+            }
+        }
     }
 }
 

@@ -427,9 +427,45 @@ static hipError_t launch_single_k(
     return hipErrorInvalidValue;
 }
 
+// cfg 4: the wide upsampler with the whole K staged once (ch = C_in = 256 /
+// 512, 16-bit operands, weights packed as one chunk)
+template <class ET, int CIN>
+static hipError_t launch_upsample_cfg(const SingleArgs& a0, hipStream_t stream) {
+    if constexpr (ET::ESZ != 2) {
+        return hipErrorNotSupported;
+    } else {
+    constexpr int WM = 4, WN = 2, MTW = 2, NTW = 2;
+    constexpr int N1 = WN * NTW * 32, MB = WM * MTW * 32;
+    SingleArgs a = a0;
+    if (a.Cin != CIN || a.M % MB) return hipErrorInvalidValue;
+    a.ntiles = (a.Lout + N1 - 1) / N1;
+    // M groups per column tile: as few as still give the chip ~2 workgroups
+    // per CU (every group stages the x tile again)
+    const int mblocks = a.M / MB;
+    int groups = 1;
+    while (groups < mblocks && (long long)a.ntiles * a.B * groups < 512)
+        groups *= 2;
+    while (mblocks % groups) groups /= 2;
+    a.nmblocks = groups;
+    auto kern = conv_upsample_kernel<ET, CIN, WM, WN, MTW, NTW>;
+    constexpr int smem = (N1 + 2) * (CIN * ET::ESZ + 16);
+    hipError_t e = pm_ensure_dynamic_lds(
+        reinterpret_cast<const void*>(kern), smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nmblocks * a.B),
+                       dim3(WM * WN * 64), smem, stream, a);
+    return hipGetLastError();
+    }
+}
+
 template <class ET>
 hipError_t pm_launch_single(
     int kind, int ch, int cfg, const SingleArgs& a, hipStream_t s) {
+    if (kind == 1 && cfg == 4) {
+        if (ch == 256) return launch_upsample_cfg<ET, 256>(a, s);
+        if (ch == 512) return launch_upsample_cfg<ET, 512>(a, s);
+        return hipErrorInvalidValue;
+    }
     if (kind == 0) return launch_single_k<ET, 7, 7>(ch, cfg, a, s);
     if (kind == 1) return launch_single_k<ET, 2, 3>(ch, cfg, a, s);
     return hipErrorInvalidValue;
