@@ -167,16 +167,18 @@ def test_whole_block(device, dtype, channels, kernel_size):
         assert rel_err(from_cl(out, channels), want) < tolerance, (length, mode)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'f16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
 @pytest.mark.parametrize(
     'c_in,c_out,rate',
     [(512, 256, 8), (256, 128, 8), (128, 64, 2), (64, 32, 2), (64, 32, 8),
      (32, 16, 2), (16, 8, 4)])
 def test_conv_transpose(device, dtype, c_in, c_out, rate):
+    # (the two wide r = 8 shapes run conv_upsample_kernel with 16-bit operands:
+    # 130 / 300 columns = 2 / 3 column tiles, M groups of several 256-row blocks)
     _lib = lib()
     gen = torch.Generator().manual_seed(c_in + rate)
     k = 2 * rate
-    for length in (1, 5, 130):
+    for length in (1, 5, 130, 300):
         x = torch.randn(2, c_in, length, generator=gen)
         w = torch.randn(c_in, c_out, k, generator=gen) / (c_in * 2) ** .5
         bias = torch.randn(c_out, generator=gen) * .1
