@@ -1006,7 +1006,6 @@ __device__ __forceinline__ void block3_body(
     constexpr int MA = 5 * H2;             // margin of `a` (max dilation 5)
     constexpr int S = C * ET::ESZ + 16;
     constexpr int ROWS_A = NC + 2 * MA;
-    constexpr int ROWS_T = NC + 2 * H2;
     constexpr int G = (ET::ESZ == 4) ? 2 : KC;
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;          // bias step of a stream
