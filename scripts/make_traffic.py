@@ -23,8 +23,10 @@ def label(kernel):
         return 'out_conv_tanh'
     if re.match(r'conv_single_kernel<\w+,7,7,', kernel):
         return 'input_conv'
-    # polyphase upsamplers: the 128- and 64-row variants are one launch each;
-    # the 256-row-tile variant serves two layers (skipped: ambiguous average)
+    # polyphase upsamplers: one kernel variant per layer
+    m = re.match(r'conv_upsample_kernel<\w+,(\d+),', kernel)
+    if m:
+        return f'convT_c{m.group(1)}_r8'
     if re.match(r'conv_single_kernel<\w+,2,3,64,4,2,1,2,0>', kernel):
         return 'convT_c128_r2'
     if re.match(r'conv_single_kernel<\w+,2,3,64,2,2,1,2,0>', kernel):
