@@ -424,8 +424,9 @@ struct FgLds {
     float f1[FG_HOP];
     float prev[FG_PREV];
     float own[64];             // this member's slice of a row-split output
-    float part[FG_THREADS];
+    float part[FG_THREADS];    // reduction buffer P (and the exchanges')
     float part2[FG_THREADS];
+    float part3[FG_THREADS];   // reduction buffer Q (see fg_slice)
 };
 static_assert(sizeof(FgLds) % 16 == 0, "16-byte aligned per-utterance state");
 #define FG_OFF(field) (offsetof(FgLds, field) / sizeof(float))
@@ -581,7 +582,8 @@ __device__ __forceinline__ void fg_exchange_sum(
         }
         total[u] = t;
     }
-    __syncthreads();
+    // no trailing barrier: the next writer of buffer P is at least one
+    // barrier away (see fg_slice)
 }
 
 // RW rows (r0 .. r0 + RW of a matrix packed with RPAD rows) of y_u = W x_u
@@ -590,10 +592,18 @@ __device__ __forceinline__ void fg_exchange_sum(
 // fields xa / xb of every FgLds); partial sums meet in LDS. sum[u] is valid
 // in threads tid < RW. Row split: RW = R / 8 rows of the full-K matrix;
 // K split: all RW = RPAD = R rows of this member's (R x K / 8) sub-matrix.
-template <class WT, int RW, int RPAD, int U, int KPAD>
+// PB: which of the two reduction buffers (P = `part`, Q = `part3`) the partial
+// sums meet in. There is NO barrier behind the reduction: consecutive slices
+// (and the partial-sum exchange, which uses P) alternate buffers, so the next
+// writer of a buffer is always at least one barrier - the next slice's own, or
+// the caller's before it touches the next input vector - behind its readers.
+template <class WT, int RW, int RPAD, int U, int KPAD, int PB>
 __device__ __forceinline__ void fg_slice(
     const WT* __restrict__ w, const float* lds, int xa, int xb, int split,
     int r0, float* ldsw, int tid, float (&sum)[U]) {
+    // (with four utterances in lockstep the registers are tight: the
+    // per-thread addresses of a slice are computed here, not earlier)
+    if constexpr (U >= 4) asm volatile("" : "+v"(tid));
     constexpr int VEC = FgVec<WT>::VEC;
     constexpr int PARTS = FG_THREADS / RW;
     constexpr int BLOCKS = KPAD / VEC;
@@ -650,9 +660,10 @@ __device__ __forceinline__ void fg_slice(
             for (int i = 0; i < R; ++i) cur[i] = nxt[i];
         }
     }
+    constexpr int PBUF = PB ? FG_OFF(part3) : FG_OFF(part);
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        ldsw[u * FG_LSTRIDE + FG_OFF(part) + tid] = acc0[u] + acc1[u];
+        ldsw[u * FG_LSTRIDE + PBUF + tid] = acc0[u] + acc1[u];
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -660,11 +671,10 @@ __device__ __forceinline__ void fg_slice(
         if (tid < RW) {
 #pragma unroll
             for (int q = 0; q < PARTS; ++q)
-                t += lds[u * FG_LSTRIDE + FG_OFF(part) + tid + q * RW];
+                t += lds[u * FG_LSTRIDE + PBUF + tid + q * RW];
         }
         sum[u] = t;
     }
-    __syncthreads();
 }
 
 struct FarganClusterArgs {
@@ -770,7 +780,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
             __syncthreads();
             float v[U], m[U], tot[U], ext[U];
             // ---- conditioning network (fargan.py:139-160): R, K, R ----
-            fg_slice<WT, 48, 384, U, CPAD>(w.cond(0), lds, FG_OFF(condin),
+            fg_slice<WT, 48, 384, U, CPAD, 0>(w.cond(0), lds, FG_OFF(condin),
                                            FG_OFF(condin), CPAD, g * 48, lds,
                                            tid, v);
             if (tid < 48) {
@@ -778,7 +788,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 for (int u = 0; u < U; ++u) L[u].c1[g * 48 + tid] = tanhf(v[u]);
             }
             __syncthreads();
-            fg_slice<WT, 384, 384, U, 48>(w.k_cond1(g), lds,
+            fg_slice<WT, 384, 384, U, 48, 1>(w.k_cond1(g), lds,
                                           FG_OFF(c1) + g * 48,
                                           FG_OFF(c1) + g * 48, 48, 0, lds, tid, v);
             fg_exchange_sum<U, 384, 0>(c, v, v, lds, tid, tot, ext);
@@ -787,7 +797,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 for (int u = 0; u < U; ++u) L[u].c2[tid] = tanhf(tot[u]);
             }
             __syncthreads();
-            fg_slice<WT, 64, 512, U, CPAD>(w.cond(2), lds, FG_OFF(c2), FG_OFF(c2),
+            fg_slice<WT, 64, 512, U, CPAD, 1>(w.cond(2), lds, FG_OFF(c2), FG_OFF(c2),
                                            CPAD, g * 64, lds, tid, v);
 #pragma unroll
             for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
@@ -821,7 +831,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 FG_STAMP(0);
 
                 // ---- framewise conv (R) + its GLU gate (K): 1 exchange ----
-                fg_slice<WT, 32, 256, U, 520>(w.fwconv(), lds, FG_OFF(subin),
+                fg_slice<WT, 32, 256, U, 520, 0>(w.fwconv(), lds, FG_OFF(subin),
                                               FG_OFF(subin), 520, g * 32, lds,
                                               tid, v);
                 FG_STAMP(1);
@@ -831,7 +841,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     if (tid < 32) L[u].own[tid] = m[u];
                 }
                 __syncthreads();
-                fg_slice<WT, 256, 256, U, 32>(
+                fg_slice<WT, 256, 256, U, 32, 1>(
                     w.k_fwconv_glu(g), lds, FG_OFF(own),
                     FG_OFF(own), 32, 0, lds, tid, v);
                 FG_STAMP(2);
@@ -852,10 +862,10 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     const int hoff = FG_OFF(hid) + n * FG_HOP;
                     // this member's 32 units x 3 gates = packed rows g*96 ..
                     float gi[U], gh[U];
-                    fg_slice<WT, 96, 768, U, 384>(w.gru_ih(n), lds, xa,
+                    fg_slice<WT, 96, 768, U, 384, 1>(w.gru_ih(n), lds, xa,
                                                   FG_OFF(skipbuf) + 1024, 256,
                                                   g * 96, lds, tid, gi);
-                    fg_slice<WT, 96, 768, U, 256>(w.gru_hh(n), lds, hoff, hoff, 256,
+                    fg_slice<WT, 96, 768, U, 256, 0>(w.gru_hh(n), lds, hoff, hoff, 256,
                                                   g * 96, lds, tid, gh);
                     FG_STAMP(4 + 4 * n);
                     if (tid < 96) {
@@ -881,7 +891,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     }
                     __syncthreads();
                     FG_STAMP(5 + 4 * n);
-                    fg_slice<WT, 256, 256, U, 32>(
+                    fg_slice<WT, 256, 256, U, 32, 1>(
                         w.k_gru_glu(n, g), lds, FG_OFF(own),
                         FG_OFF(own), 32, 0, lds, tid, v);
                     FG_STAMP(6 + 4 * n);
@@ -900,7 +910,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
 
                 // ---- skip dense (R): vector exchange ----
                 FG_STAMP(16);
-                fg_slice<WT, 32, 256, U, FG_SKIP>(w.skip(), lds, FG_OFF(skipbuf),
+                fg_slice<WT, 32, 256, U, FG_SKIP, 1>(w.skip(), lds, FG_OFF(skipbuf),
                                                   FG_OFF(skipbuf), FG_SKIP, g * 32,
                                                   lds, tid, v);
                 FG_STAMP(17);
@@ -909,7 +919,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 fg_exchange<U, 32>(c, m, lds, FG_OFF(f1), tid);
                 FG_STAMP(18);
                 // ---- skip GLU (R) + output layer (K): 1 exchange ----
-                fg_slice<WT, 32, 256, U, 256>(w.skip_glu(), lds, FG_OFF(f1), FG_OFF(f1),
+                fg_slice<WT, 32, 256, U, 256, 0>(w.skip_glu(), lds, FG_OFF(f1), FG_OFF(f1),
                                               256, g * 32, lds, tid, v);
                 if (tid < 32) {
 #pragma unroll
@@ -918,7 +928,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 __syncthreads();
                 FG_STAMP(19);
-                fg_slice<WT, 64, 64, U, 32>(w.k_out(g), lds,
+                fg_slice<WT, 64, 64, U, 32, 1>(w.k_out(g), lds,
                                             FG_OFF(own), FG_OFF(own), 32, 0, lds,
                                             tid, v);
                 FG_STAMP(20);
