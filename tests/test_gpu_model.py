@@ -415,13 +415,15 @@ def test_mel(device):
     got = promonet_amd.preprocess.spectrogram.from_audio(
         audio.to(device), mels=True)
     assert got.shape == want.shape == (2, 80, 40)
-    assert max_abs(got, want) < 1e-4
+    # STFT / mel <= 2e-5 abs + 1e-5 rel (measured: 2.1e-6)
+    assert ((got.cpu() - want).abs() <= 2e-5 + 1e-5 * want.abs()).all()
     basis = promonet_amd.preprocess.spectrogram.mel_basis()
     assert max_abs(basis, oracle.mel_basis()) < 1e-7
     clamped = promonet_amd.preprocess.spectrogram.from_audio(
         audio.to(device), mels=True,
         log_dynamic_range_compression_threshold=-1.)
-    assert max_abs(clamped, torch.clamp(want, min=-1.)) < 1e-4
+    floor = torch.clamp(want, min=-1.)
+    assert ((clamped.cpu() - floor).abs() <= 2e-5 + 1e-5 * floor.abs()).all()
 
 
 def test_spectrogram_backward(device):
@@ -476,13 +478,16 @@ def test_loudness(device):
         got = promonet_amd.preprocess.loudness.from_audio(
             audio.to(device), bands)
         assert got.shape == want.shape
-        assert max_abs(got, want) < 2e-3, bands          # dB
+        # dB over a 100 dB range; measured 3e-5 (bands) / 2.7e-4 (per bin)
+        assert ((got.cpu() - want).abs() <= 1e-4 + 1e-5 * want.abs()).all(), \
+            bands
     # batched: each utterance keeps its own floor
     pair = torch.cat([audio, audio * .01])
     got = promonet_amd.preprocess.loudness.from_audio(pair.to(device), 8)
     for item in range(2):
         want = oracle.loudness(pair[item:item + 1], 8)
-        assert max_abs(got[item], want) < 2e-3
+        assert ((got[item].cpu() - want).abs() <=
+                1e-4 + 1e-5 * want.abs()).all()
 
 
 def test_ragged_batch_is_exact(device, default_state):
