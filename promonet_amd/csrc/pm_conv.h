@@ -10,15 +10,28 @@
 // write), K = (input channel, tap). A tap / dilation is a row offset into the
 // LDS tile, so the tile is read k times from LDS and once from HBM.
 //
-// Two kernels:
-//   conv_pair_kernel    one HiFi-GAN `Block` iteration fused:
-//                       y = x + conv2(lrelu(conv1(lrelu(x))))      hifigan.py:198-210
-//                       (conv1 output never leaves LDS), optional MRF
-//                       accumulation epilogue (xs / 3, hifigan.py:141-145)
-//   conv_single_kernel  generic C_in -> M conv with per-M-tile tap windows;
-//                       runs the input conv (hifigan.py:19-24) and, as an
-//                       r-phase polyphase GEMM, the ConvTranspose1d
-//                       upsamplers (hifigan.py:100-106).
+// Kernels:
+//   conv_pair_kernel     one HiFi-GAN `Block` iteration fused:
+//                        y = x + conv2(lrelu(conv1(lrelu(x))))     hifigan.py:198-210
+//                        (conv1 output never leaves LDS; the fp32 residual is
+//                        loaded into the conv1 accumulators and conv2
+//                        accumulates onto it), optional MRF accumulation
+//                        epilogue (xs / 3, hifigan.py:141-145); C = 128, 256
+//   conv_block3_kernel   a whole `Block` (all dilations) with the fp32 trunk in
+//                        registers; C <= 64, and C = 128 at k 3
+//   conv_mrf_kernel      a whole MRF stage (Blocks k 3, 7, 11) with the sum in
+//                        registers; C = 32
+//   conv_single_kernel   generic C_in -> M conv with per-M-tile tap windows:
+//                        the input conv (hifigan.py:19-24), the narrow
+//                        ConvTranspose1d upsamplers as r-phase polyphase GEMMs
+//                        (hifigan.py:100-106), the framed DFT of the STFT
+//   conv_upsample_kernel the wide (r = 8) upsamplers: x tile staged once, all M
+//                        blocks walked by one workgroup
+// Every access that can meet an utterance edge or a tile's halo goes through a
+// buffer descriptor whose range is exactly the rows that exist (loads return
+// 0, stores are dropped): no per-lane branches, exact vmcnt arithmetic.
+// Workgroup barriers fence LDS only (pm_block_sync), so global loads stay in
+// flight across them.
 #pragma once
 #include "pm_common.h"
 
