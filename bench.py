@@ -48,9 +48,9 @@ FARGAN_WEIGHTS = 2_246_656 + (2 * 371 * 371 + 512 * 371) // 4
 PEAK_TFLOPS = {'f16': 2500., 'bf16': 2500., 'fp32': 157.3}   # dense MFMA
 PEAK_HBM_GBS = 8000.
 # sustained register-resident MFMA rate on random operands under the power cap
-# (scripts/micro/mfma_peak.hip, profiles/r01/micro_mfma.txt): what an MFMA
+# (scripts/micro/mfma_shapes.hip, profiles/r02/micro_mfma_shapes.txt): what an MFMA
 # kernel can reach on this part; reported beside the nominal peak
-SUSTAINED_TFLOPS = {'f16': 1650., 'bf16': 1650.}
+SUSTAINED_TFLOPS = {'f16': 1700., 'bf16': 1850.}
 
 
 def parse_args():
