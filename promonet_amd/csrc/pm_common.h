@@ -80,8 +80,12 @@ struct ElemF16 {
     // bias step (pm_pack_bias_step_kernel): c += b[co] for every column
     __device__ static __forceinline__ void mma_bias(
         const frag_t& a, floatx16& c) {
-        const _Float16 one = (_Float16)1.f;
-        const frag_t ones = {one, one, one, one, one, one, one, one};
+        // (an opaque constant, materialised at the use: as a loop invariant
+        // of a long kernel the four registers of the fragment get spilled)
+        unsigned pair = 0x3c003c00u;            // {1.0h, 1.0h}
+        asm volatile("" : "+v"(pair));
+        const pm_u4 bits = {pair, pair, pair, pair};
+        const frag_t ones = __builtin_bit_cast(frag_t, bits);
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, c, 0, 0, 0);
     }
 };
@@ -106,8 +110,10 @@ struct ElemBF16 {
     __device__ static __forceinline__ lds_t cvt(float v) { return (__bf16)v; }
     __device__ static __forceinline__ void mma_bias(
         const frag_t& a, floatx16& c) {
-        const __bf16 one = (__bf16)1.f;
-        const frag_t ones = {one, one, one, one, one, one, one, one};
+        unsigned pair = 0x3f803f80u;            // {1.0bf16, 1.0bf16}
+        asm volatile("" : "+v"(pair));
+        const pm_u4 bits = {pair, pair, pair, pair};
+        const frag_t ones = __builtin_bit_cast(frag_t, bits);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, c, 0, 0, 0);
     }
 };

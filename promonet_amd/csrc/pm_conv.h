@@ -1002,12 +1002,35 @@ __host__ __device__ constexpr int block3_smem_bytes() {
 // into the conv1 accumulators (dead from there on), and hand it over in
 // `xnext`: the round trip runs under the last conv2 instead of in front of
 // the next Block's first conv.
+// WALK (conv_mrf_walk_kernel): the workgroup walks consecutive tiles of one
+// utterance segment, left to right, and every layer's input keeps its last
+// columns in a small LDS "carry" area, from where the next tile fills its LEFT
+// margins. The left halo is then exact context instead of recomputed garbage:
+// a tile is valid from its first column, only the right halo (a.halo columns)
+// is recomputed by the next tile - half the redundant work. Same arithmetic per
+// column, so results are bit-identical to the two-sided tiling.
+struct B3Walk {
+    int b;            // utterance
+    int c_first;      // time of the tile's column 0
+    int store_lo;     // first column this tile stores
+    int store_n;      // columns it stores
+    int left;         // 1: left margins come from the carry area
+    char* carry;      // this Block's carry area (niter x (MA + H2) rows)
+    // the Block's weight streams and dilations, read straight from the
+    // kernel-argument segment (scalar loads with a run-time iteration index;
+    // a by-value copy indexed at run time would live in scratch)
+    const void* const __attribute__((address_space(4)))* w1;
+    const void* const __attribute__((address_space(4)))* w2;
+    const int __attribute__((address_space(4)))* dil;
+};
+
 template <class ET, int C, int K, int WM, int WN, int NTW, int SUM = 0,
-          int XMODE = 0>
+          int XMODE = 0, int WALK = 0>
 __device__ __forceinline__ void block3_body(
     const Block3Args& a, char* smem,
     floatx16 (&sum)[(C / 32) / WM][NTW],
-    floatx16 (&xnext)[(C / 32) / WM][NTW]) {
+    floatx16 (&xnext)[(C / 32) / WM][NTW],
+    const B3Walk* wk = nullptr) {
     typedef typename ET::frag_t frag_t;
     constexpr int CH = C < 64 ? C : 64;    // weight-stream chunk (as packed)
     constexpr int NCH = C / CH;
@@ -1027,7 +1050,10 @@ __device__ __forceinline__ void block3_body(
     char* abuf = smem;
     char* tbuf = smem + ROWS_A * S;
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    // (walked: everything derived from the thread id is recomputed per tile -
+    // hoisted out of the walk it is carried, i.e. spilled, across it)
+    if constexpr (WALK) asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -1035,24 +1061,63 @@ __device__ __forceinline__ void block3_body(
     const int ln = lane & 31, lh = lane >> 5;
     if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);   // see the pair kernel
 
-    const int wg = pm_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = wg % a.ntiles;
-    const int b = wg / a.ntiles;
+    int b, c_first, store_lo, store_n;
+    if constexpr (WALK) {
+        b = wk->b; c_first = wk->c_first;
+        store_lo = wk->store_lo; store_n = wk->store_n;
+    } else {
+        const int wg = pm_xcd_remap(blockIdx.x, gridDim.x);
+        const int tile = wg % a.ntiles;
+        b = wg / a.ntiles;
+        c_first = tile * a.TL - a.halo;   // time of column 0
+        store_lo = a.halo; store_n = a.TL;
+    }
     const int L = a.lengths ? min(a.lengths[b] * a.len_scale, a.L) : a.L;
-    if (tile * a.TL >= L) return;
-    const int c_first = tile * a.TL - a.halo;   // time of column 0
+    if constexpr (!WALK) {
+        if (c_first + a.halo >= L) return;
+    }
     const float* __restrict__ xb = a.x + (size_t)b * a.L * C;
     PM_STAMP(a, 0);
+    // carry strips: rows [NC - halo - m, NC - halo) of a layer's input, which
+    // the next tile (c_first + NC - halo) needs as columns [-m, 0)
+    constexpr int QS16 = S / 16;
+    [[maybe_unused]] const int keep = NC - a.halo;
+    // (two strips in one pass over disjoint threads: the copies are a few
+    // hundred bytes each and latency-bound, so they run side by side)
+    [[maybe_unused]] auto strip_copy2 = [&](
+        char* dst_a, const char* src_a, int rows_a, char* dst_b,
+        const char* src_b, int rows_b) {
+        const int na = rows_a * QS16, nb = rows_b * QS16;
+        for (int i = tid; i < na + nb; i += NT) {
+            const bool second = i >= na;
+            const int k = second ? i - na : i;
+            const float4 v = reinterpret_cast<const float4*>(
+                second ? src_b : src_a)[k];
+            reinterpret_cast<float4*>(second ? dst_b : dst_a)[k] = v;
+        }
+    };
 
     // ---- zero the margins (they stand for neighbours' columns: only ever
     // feed the recomputed halo, but must be finite) ------------------------
     {
         constexpr int QS = S / 16;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (walked: an opaque zero, materialised here - as a loop invariant of
+        // the walk the four registers were spilled)
+        float zero = 0.f;
+        if constexpr (WALK) asm volatile("" : "+v"(zero));
+        const float4 z = make_float4(zero, zero, zero, zero);
         for (int i = tid; i < 2 * MA * QS; i += NT) {
             const int r = i / QS, q = i % QS;
             const int row = r < MA ? r : NC + r;
             *reinterpret_cast<float4*>(abuf + row * S + q * 16) = z;
+        }
+        if constexpr (WALK) {
+            // (same threads, same addresses as the zero fill above: program
+            // order) the previous tile's last columns of a_0 = lrelu(x)
+            if (wk->left)
+                for (int i = tid; i < MA * QS; i += NT)
+                    reinterpret_cast<float4*>(abuf)[i] =
+                        reinterpret_cast<const float4*>(wk->carry)[i];
         }
         for (int i = tid; i < 2 * H2 * QS; i += NT) {
             const int r = i / QS, q = i % QS;
@@ -1114,7 +1179,10 @@ __device__ __forceinline__ void block3_body(
     frag_t bf[MTW];
     frag_t afirst[G][MTW];
     {
-        const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1[0]) +
+        const void* first_stream;
+        if constexpr (WALK) first_stream = wk->w1[0];
+        else first_stream = a.w1[0];
+        const frag_t* w1 = reinterpret_cast<const frag_t*>(first_stream) +
                            (size_t)(wm * MTW) * W_MT_STRIDE + lane;
         load_bias_frags<ET, MTW>(bf, w1 + W_BIAS, W_MT_STRIDE);
         load_a_group<ET, MTW, G>(afirst, w1, W_MT_STRIDE);
@@ -1123,10 +1191,17 @@ __device__ __forceinline__ void block3_body(
 
 #pragma unroll 1
     for (int it = 0; it < a.niter; ++it) {
-        const int d = a.dil[it];
-        const frag_t* w1 = reinterpret_cast<const frag_t*>(a.w1[it]) +
+        auto stream1 = [&](int i) -> const void* {
+            if constexpr (WALK) return wk->w1[i]; else return a.w1[i];
+        };
+        auto stream2 = [&](int i) -> const void* {
+            if constexpr (WALK) return wk->w2[i]; else return a.w2[i];
+        };
+        int d;
+        if constexpr (WALK) d = wk->dil[it]; else d = a.dil[it];
+        const frag_t* w1 = reinterpret_cast<const frag_t*>(stream1(it)) +
                            (size_t)(wm * MTW) * W_MT_STRIDE + lane;
-        const frag_t* w2 = reinterpret_cast<const frag_t*>(a.w2[it]) +
+        const frag_t* w2 = reinterpret_cast<const frag_t*>(stream2(it)) +
                            (size_t)(wm * MTW) * W_MT_STRIDE + lane;
 
         // ---- conv1 (dilation d) out of `a` ----
@@ -1138,19 +1213,37 @@ __device__ __forceinline__ void block3_body(
                 c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
         PM_STAMP(a, 2 + 4 * it);
         load_bias_frags<ET, MTW>(bf, w2 + W_BIAS, W_MT_STRIDE);
+        if constexpr (WALK) {
+            // `a` is stable until this iteration's epilogue 2 (behind the
+            // next barrier): keep its last exact columns for the next tile;
+            // and the left margin of `t` (last read by the previous conv2,
+            // two barriers ago) takes the previous tile's columns
+            char* cit = wk->carry + it * (MA + H2) * S;
+            strip_copy2(cit, abuf + keep * S, MA, tbuf, cit + MA * S,
+                        wk->left ? H2 : 0);
+        }
+        // (walked: epilogue addresses from a fresh copy of the thread id, so
+        // that they are not carried across the MFMA loops)
+        int te = tid;
+        if constexpr (WALK) asm volatile("" : "+v"(te));
+        const int ln1 = te & 31, lh1 = (te >> 5) & 1;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int col_first = (wn * NTW + nt) * 32;
-                const int col = col_first + ln;
+                const int col = col_first + ln1;
                 const int t_tile = c_first + col_first;
                 store_tile_lrelu<ET>(tbuf + (H2 + col) * S, m_first + mt * 32,
-                                     acc[mt][nt], t_tile, L, ln, lh);
+                                     acc[mt][nt], t_tile, L, ln1, lh1);
                 if constexpr (XMODE & 2) {
                     if (it + 1 == a.niter) {
+                        const unsigned xv = WALK
+                            ? (unsigned)(((c_first - x_lo + wn * NTW * 32 + ln1) *
+                                          C + m_first + 4 * lh1) * 4)
+                            : xvoff0;
                         const unsigned voff =
-                            xvoff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+                            xv + (unsigned)((mt * 32 + nt * 32 * C) * 4);
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
                             const pm_u4 v =
@@ -1179,25 +1272,37 @@ __device__ __forceinline__ void block3_body(
                 c + 1 < NCH
                     ? w2 + (size_t)(c + 1) * W_CHUNK
                     : (last ? nullptr
-                            : reinterpret_cast<const frag_t*>(a.w1[it + 1]) +
+                            : reinterpret_cast<const frag_t*>(stream1(it + 1)) +
                                   (size_t)(wm * MTW) * W_MT_STRIDE + lane));
         PM_STAMP(a, 4 + 4 * it);
         if (!last)
             load_bias_frags<ET, MTW>(
-                bf, reinterpret_cast<const frag_t*>(a.w1[it + 1]) +
+                bf, reinterpret_cast<const frag_t*>(stream1(it + 1)) +
                         (size_t)(wm * MTW) * W_MT_STRIDE + lane + W_BIAS,
                 W_MT_STRIDE);
+        if constexpr (WALK) {
+            // `t` is stable until the next iteration's epilogue 1: keep its
+            // last exact columns; the left margin of `a` (last read by this
+            // iteration's conv1, behind a barrier) takes the previous tile's
+            // columns of the NEXT iteration's input
+            char* cit = wk->carry + it * (MA + H2) * S;
+            strip_copy2(cit + MA * S, tbuf + keep * S, H2, abuf,
+                        cit + (MA + H2) * S, !last && wk->left ? MA : 0);
+        }
+        int tf = tid;
+        if constexpr (WALK) asm volatile("" : "+v"(tf));
+        const int ln2 = tf & 31, lh2 = (tf >> 5) & 1;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 if (!last) {
                     const int col_first = (wn * NTW + nt) * 32;
-                    const int col = col_first + ln;
+                    const int col = col_first + ln2;
                     const int t_tile = c_first + col_first;
                     store_tile_lrelu<ET>(abuf + (MA + col) * S,
                                          m_first + mt * 32, trunk[mt][nt],
-                                         t_tile, L, ln, lh);
+                                         t_tile, L, ln2, lh2);
                 }
             }
         if (!last) bias_start<ET, MTW, NTW>(acc, bf);
@@ -1233,12 +1338,20 @@ __device__ __forceinline__ void block3_body(
     // dropped, loads 0) - no per-lane branches.
     const int mode = SUM == 3 ? 1 : a.mode;
     const float scale = a.scale;
-    const int own_first = tile * a.TL;
+    const int own_first = c_first + store_lo;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         a.out + ((size_t)b * a.L + own_first) * C, 0,
-        min(a.TL, L - own_first) * C * 4, 0x00020000);
+        max(min(store_n, L - own_first), 0) * C * 4, 0x00020000);
+    // (walked: the store offsets are computed here from a fresh copy of the
+    // thread id - derived at the top of the Block they would be carried, and
+    // spilled, across all of it)
+    int tid_s = tid;
+    if constexpr (WALK) asm volatile("" : "+v"(tid_s));
+    const int lane_s = tid_s & 63;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid_s >> 6);
     const unsigned ovoff0 = (unsigned)(
-        ((wn * NTW * 32 + ln - a.halo) * C + m_first + 4 * lh) * 4);
+        (((wave_s % WN) * NTW * 32 + (lane_s & 31) - store_lo) * C +
+         (wave_s / WN) * MTW * 32 + 4 * (lane_s >> 5)) * 4);
     if (mode == 2) {
         // the reads of `out` go out in batches before the first store of a
         // batch: one round trip per batch, not per 32 x 32 tile
@@ -1348,5 +1461,88 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_kernel(MrfArgs m) {
         block3_body<ET, C, 7, WM, WN, NTW>(m.k[1], smem, sum, sum);
         pm_block_sync();
         block3_body<ET, C, 11, WM, WN, NTW>(m.k[2], smem, sum, sum);
+    }
+}
+
+// Whole MRF stage, walked (B3Walk): one workgroup per (utterance, segment)
+// processes its tiles left to right; only a segment's first tile pays the
+// two-sided halo. Carry areas of the three Blocks sit behind the k = 11 LDS
+// layout.
+template <class ET, int C, int K>
+__host__ __device__ constexpr int block3_carry_bytes(int niter) {
+    return niter * (5 * ((K - 1) / 2) + (K - 1) / 2) * (C * ET::ESZ + 16);
+}
+
+// (compact arguments: the three Blocks share everything but their weights
+// and dilations, and all of it stays live across the walk)
+struct MrfWalkArgs {
+    const float* x;
+    float* out;
+    const void* w1[3][3];   // [Block k 3 / 7 / 11][iteration]
+    const void* w2[3][3];
+    int dil[3][3];
+    int B, L, halo;
+    float scale;
+    const int* lengths;
+    int len_scale;
+    int nseg;               // segments per utterance
+};
+
+template <class ET, int C, int WM, int WN, int NTW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_mrf_walk_kernel(
+    MrfWalkArgs m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NC = WN * NTW * 32;
+    const int H = m.halo;
+    const int b = blockIdx.x / m.nseg, seg = blockIdx.x % m.nseg;
+    const int L = m.lengths ? min(m.lengths[b] * m.len_scale, m.L) : m.L;
+    // segment boundaries: multiples of 32 columns
+    const int per = (((L + m.nseg - 1) / m.nseg) + 31) & ~31;
+    const int s0 = seg * per;
+    const int e0 = min(L, s0 + per);
+    if (s0 >= e0) return;
+
+    char* carry11 = smem + block3_smem_bytes<ET, C, 11, WM, WN, NTW>();
+    char* carry7 = carry11 + block3_carry_bytes<ET, C, 11>(3);
+    char* carry3 = carry7 + block3_carry_bytes<ET, C, 7>(3);
+
+    Block3Args common = {};     // (its weight / dilation arrays stay unused)
+    common.x = m.x; common.out = m.out; common.niter = 3;
+    common.B = m.B; common.L = m.L; common.mode = 1; common.scale = m.scale;
+    common.halo = H; common.lengths = m.lengths; common.len_scale = m.len_scale;
+    const MrfWalkArgs __attribute__((address_space(4)))* karg =
+        (const MrfWalkArgs __attribute__((address_space(4)))*)
+            __builtin_amdgcn_kernarg_segment_ptr();
+    auto block = [&](B3Walk& w, int j, char* carry) {
+        w.carry = carry;
+        w.w1 = karg->w1[j]; w.w2 = karg->w2[j]; w.dil = karg->dil[j];
+    };
+
+    floatx16 sum[(C / 32) / WM][NTW];
+    floatx16 xnext[(C / 32) / WM][NTW];
+    int own = s0;          // next column to store
+    int left = 0;
+#pragma unroll 1
+    while (own < e0) {
+        B3Walk w;
+        w.b = b;
+        w.c_first = left ? own : (s0 == 0 ? 0 : own - H);
+        w.store_lo = own - w.c_first;
+        w.store_n = min(NC - H - w.store_lo, e0 - own);
+        w.left = left;
+        block(w, 2, carry11);
+        block3_body<ET, C, 11, WM, WN, NTW, 1, 2, 1>(
+            common, smem, sum, xnext, &w);
+        pm_block_sync();
+        block(w, 1, carry7);
+        block3_body<ET, C, 7, WM, WN, NTW, 2, 3, 1>(
+            common, smem, sum, xnext, &w);
+        pm_block_sync();
+        block(w, 0, carry3);
+        block3_body<ET, C, 3, WM, WN, NTW, 3, 1, 1>(
+            common, smem, sum, xnext, &w);
+        pm_block_sync();
+        own += w.store_n;
+        left = 1;
     }
 }

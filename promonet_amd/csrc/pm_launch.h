@@ -308,6 +308,47 @@ static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stre
         m.k[j].timeline = nullptr;
 #endif
     }
+    // Walked variant (no left-halo recompute): one workgroup per (utterance,
+    // segment) with enough tiles per segment to amortise its two-sided first
+    // tile; the sum-in-registers geometry (C = 32) only.
+    if constexpr (C == 32 && ET::ESZ == 2 && WM * WN == 8) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
+                                  dev) == hipSuccess && cus > 0 &&
+            m.k[0].niter == 3 && m.k[1].niter == 3 && m.k[2].niter == 3) {
+            const int B = m.k[0].B, L = m.k[0].L;
+            const int step = NC - halo;
+            int nseg = cus / B;
+            if (nseg < 1) nseg = 1;
+            const int tiles_per_seg = (L / step) / nseg;
+            if (tiles_per_seg >= 8) {
+                MrfWalkArgs wa = {};
+                wa.x = m.k[0].x; wa.out = m.k[0].out;
+                for (int j = 0; j < 3; ++j)
+                    for (int n = 0; n < 3; ++n) {
+                        wa.w1[j][n] = m.k[j].w1[n];
+                        wa.w2[j][n] = m.k[j].w2[n];
+                        wa.dil[j][n] = m.k[j].dil[n];
+                    }
+                wa.B = B; wa.L = L; wa.halo = halo; wa.scale = m.k[0].scale;
+                wa.lengths = m.k[0].lengths; wa.len_scale = m.k[0].len_scale;
+                wa.nseg = nseg;
+                auto walk = conv_mrf_walk_kernel<ET, C, WM, WN, NTW>;
+                constexpr int smem_walk =
+                    block3_smem_bytes<ET, C, 11, WM, WN, NTW>() +
+                    block3_carry_bytes<ET, C, 11>(3) +
+                    block3_carry_bytes<ET, C, 7>(3) +
+                    block3_carry_bytes<ET, C, 3>(3);
+                hipError_t e = pm_ensure_dynamic_lds(
+                    reinterpret_cast<const void*>(walk), smem_walk);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(walk, dim3(B * nseg), dim3(WM * WN * 64),
+                                   smem_walk, stream, wa);
+                return hipGetLastError();
+            }
+        }
+    }
     auto kern = conv_mrf_kernel<ET, C, WM, WN, NTW, C == 32>;
     constexpr int smem = block3_smem_bytes<ET, C, 11, WM, WN, NTW>();
     hipError_t e = pm_ensure_dynamic_lds(
