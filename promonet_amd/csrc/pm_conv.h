@@ -1011,6 +1011,7 @@ __host__ __device__ constexpr int block3_smem_bytes() {
 // column, so results are bit-identical to the two-sided tiling.
 struct B3Walk {
     int b;            // utterance
+    int L;            // its length in columns
     int c_first;      // time of the tile's column 0
     int store_lo;     // first column this tile stores
     int store_n;      // columns it stores
@@ -1041,7 +1042,10 @@ __device__ __forceinline__ void block3_body(
     constexpr int H2 = (K - 1) / 2;
     constexpr int MA = 5 * H2;             // margin of `a` (max dilation 5)
     constexpr int S = C * ET::ESZ + 16;
-    constexpr int ROWS_A = NC + 2 * MA;
+    // (walked: no right margin behind `a` - the dilated taps of the last
+    // columns then read the first rows of `t`, finite values that only ever
+    // reach columns of the right halo, which the next tile recomputes)
+    constexpr int ROWS_A = NC + (WALK ? 1 : 2) * MA;
     constexpr int G = (ET::ESZ == 4) ? 2 : KC;
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;          // bias step of a stream
@@ -1072,8 +1076,11 @@ __device__ __forceinline__ void block3_body(
         c_first = tile * a.TL - a.halo;   // time of column 0
         store_lo = a.halo; store_n = a.TL;
     }
-    const int L = a.lengths ? min(a.lengths[b] * a.len_scale, a.L) : a.L;
-    if constexpr (!WALK) {
+    int L;
+    if constexpr (WALK) {
+        L = wk->L;
+    } else {
+        L = a.lengths ? min(a.lengths[b] * a.len_scale, a.L) : a.L;
         if (c_first + a.halo >= L) return;
     }
     const float* __restrict__ xb = a.x + (size_t)b * a.L * C;
@@ -1106,18 +1113,20 @@ __device__ __forceinline__ void block3_body(
         float zero = 0.f;
         if constexpr (WALK) asm volatile("" : "+v"(zero));
         const float4 z = make_float4(zero, zero, zero, zero);
-        for (int i = tid; i < 2 * MA * QS; i += NT) {
+        for (int i = tid; i < (WALK ? 1 : 2) * MA * QS; i += NT) {
             const int r = i / QS, q = i % QS;
             const int row = r < MA ? r : NC + r;
             *reinterpret_cast<float4*>(abuf + row * S + q * 16) = z;
         }
         if constexpr (WALK) {
             // (same threads, same addresses as the zero fill above: program
-            // order) the previous tile's last columns of a_0 = lrelu(x)
-            if (wk->left)
-                for (int i = tid; i < MA * QS; i += NT)
-                    reinterpret_cast<float4*>(abuf)[i] =
+            // order) the previous tile's last H2 d_0 columns of a_0 = lrelu(x)
+            if (wk->left) {
+                const int ma = H2 * wk->dil[0];
+                for (int i = tid; i < ma * QS; i += NT)
+                    reinterpret_cast<float4*>(abuf + (MA - ma) * S)[i] =
                         reinterpret_cast<const float4*>(wk->carry)[i];
+            }
         }
         for (int i = tid; i < 2 * H2 * QS; i += NT) {
             const int r = i / QS, q = i % QS;
@@ -1189,6 +1198,9 @@ __device__ __forceinline__ void block3_body(
     }
     bias_start<ET, MTW, NTW>(acc, bf);
 
+    // carry area: per iteration the last H2 d columns of `a`, then the last H2
+    // columns of `t` - a.halo rows in all
+    [[maybe_unused]] int coff = 0;
 #pragma unroll 1
     for (int it = 0; it < a.niter; ++it) {
         auto stream1 = [&](int i) -> const void* {
@@ -1218,9 +1230,10 @@ __device__ __forceinline__ void block3_body(
             // next barrier): keep its last exact columns for the next tile;
             // and the left margin of `t` (last read by the previous conv2,
             // two barriers ago) takes the previous tile's columns
-            char* cit = wk->carry + it * (MA + H2) * S;
-            strip_copy2(cit, abuf + keep * S, MA, tbuf, cit + MA * S,
-                        wk->left ? H2 : 0);
+            char* cit = wk->carry + coff;
+            const int ma = H2 * d;
+            strip_copy2(cit, abuf + (keep + MA - ma) * S, ma, tbuf,
+                        cit + ma * S, wk->left ? H2 : 0);
         }
         // (walked: epilogue addresses from a fresh copy of the thread id, so
         // that they are not carried across the MFMA loops)
@@ -1285,9 +1298,12 @@ __device__ __forceinline__ void block3_body(
             // last exact columns; the left margin of `a` (last read by this
             // iteration's conv1, behind a barrier) takes the previous tile's
             // columns of the NEXT iteration's input
-            char* cit = wk->carry + it * (MA + H2) * S;
-            strip_copy2(cit + MA * S, tbuf + keep * S, H2, abuf,
-                        cit + (MA + H2) * S, !last && wk->left ? MA : 0);
+            const int ma = H2 * d;
+            char* cit = wk->carry + coff;
+            coff += (ma + H2) * S;
+            const int ma_next = !last && wk->left ? H2 * wk->dil[it + 1] : 0;
+            strip_copy2(cit + ma * S, tbuf + keep * S, H2,
+                        abuf + (MA - ma_next) * S, wk->carry + coff, ma_next);
         }
         int tf = tid;
         if constexpr (WALK) asm volatile("" : "+v"(tf));
@@ -1468,9 +1484,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_kernel(MrfArgs m) {
 // processes its tiles left to right; only a segment's first tile pays the
 // two-sided halo. Carry areas of the three Blocks sit behind the k = 11 LDS
 // layout.
-template <class ET, int C, int K>
-__host__ __device__ constexpr int block3_carry_bytes(int niter) {
-    return niter * (5 * ((K - 1) / 2) + (K - 1) / 2) * (C * ET::ESZ + 16);
+// (a Block's carry area: halo rows; LDS of the walked layout: no right
+// margin behind `a`)
+template <class ET, int C>
+__host__ __device__ constexpr int block3_carry_bytes(int halo) {
+    return halo * (C * ET::ESZ + 16);
+}
+template <class ET, int C, int K, int WM, int WN, int NTW>
+__host__ __device__ constexpr int block3_walk_smem_bytes() {
+    constexpr int NC = WN * NTW * 32;
+    constexpr int S = C * ET::ESZ + 16;
+    return (NC + 5 * ((K - 1) / 2)) * S + (NC + (K - 1)) * S;
 }
 
 // (compact arguments: the three Blocks share everything but their weights
@@ -1502,9 +1526,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_walk_kernel(
     const int e0 = min(L, s0 + per);
     if (s0 >= e0) return;
 
-    char* carry11 = smem + block3_smem_bytes<ET, C, 11, WM, WN, NTW>();
-    char* carry7 = carry11 + block3_carry_bytes<ET, C, 11>(3);
-    char* carry3 = carry7 + block3_carry_bytes<ET, C, 7>(3);
+    // (all three Blocks are tiled with the k = 11 halo; their own carry
+    // areas need 5 / 3 / 1 twelfths of it... bounded by H rows each)
+    char* carry11 = smem + block3_walk_smem_bytes<ET, C, 11, WM, WN, NTW>();
+    char* carry7 = carry11 + block3_carry_bytes<ET, C>(H);
+    char* carry3 = carry7 + block3_carry_bytes<ET, C>(H);
 
     Block3Args common = {};     // (its weight / dilation arrays stay unused)
     common.x = m.x; common.out = m.out; common.niter = 3;
@@ -1526,9 +1552,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_walk_kernel(
     while (own < e0) {
         B3Walk w;
         w.b = b;
-        w.c_first = left ? own : (s0 == 0 ? 0 : own - H);
+        w.L = L;
+        // (readfirstlane: the walk is wave-uniform - scalar registers)
+        w.c_first = __builtin_amdgcn_readfirstlane(
+            left ? own : (s0 == 0 ? 0 : own - H));
         w.store_lo = own - w.c_first;
-        w.store_n = min(NC - H - w.store_lo, e0 - own);
+        w.store_n = __builtin_amdgcn_readfirstlane(
+            min(NC - H - w.store_lo, e0 - own));
         w.left = left;
         block(w, 2, carry11);
         block3_body<ET, C, 11, WM, WN, NTW, 1, 2, 1>(
@@ -1541,6 +1571,53 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_walk_kernel(
         block(w, 0, carry3);
         block3_body<ET, C, 3, WM, WN, NTW, 3, 1, 1>(
             common, smem, sum, xnext, &w);
+        pm_block_sync();
+        own += w.store_n;
+        left = 1;
+    }
+}
+
+// A whole Block, walked (see B3Walk): where the carry area still fits the LDS
+// beside the two operand tiles (C = 64 at k 7, C = 128 at k 3).
+struct Block3WalkArgs {
+    Block3Args a;
+    int nseg;               // segments per utterance
+};
+
+template <class ET, int C, int K, int WM, int WN, int NTW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_block3_walk_kernel(
+    Block3WalkArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NC = WN * NTW * 32;
+    const Block3Args& a = p.a;
+    const int H = a.halo;
+    const int b = blockIdx.x / p.nseg, seg = blockIdx.x % p.nseg;
+    const int L = a.lengths ? min(a.lengths[b] * a.len_scale, a.L) : a.L;
+    const int per = (((L + p.nseg - 1) / p.nseg) + 31) & ~31;
+    const int s0 = seg * per;
+    const int e0 = min(L, s0 + per);
+    if (s0 >= e0) return;
+    const Block3WalkArgs __attribute__((address_space(4)))* karg =
+        (const Block3WalkArgs __attribute__((address_space(4)))*)
+            __builtin_amdgcn_kernarg_segment_ptr();
+    B3Walk w;
+    w.b = b;
+    w.L = L;
+    w.carry = smem + block3_walk_smem_bytes<ET, C, K, WM, WN, NTW>();
+    w.w1 = karg->a.w1; w.w2 = karg->a.w2; w.dil = karg->a.dil;
+    floatx16 unused[(C / 32) / WM][NTW];
+    int own = s0, left = 0;
+#pragma unroll 1
+    while (own < e0) {
+        // (readfirstlane: the walk is wave-uniform - scalar registers)
+        w.c_first = __builtin_amdgcn_readfirstlane(
+            left ? own : (s0 == 0 ? 0 : own - H));
+        w.store_lo = own - w.c_first;
+        w.store_n = __builtin_amdgcn_readfirstlane(
+            min(NC - H - w.store_lo, e0 - own));
+        w.left = left;
+        block3_body<ET, C, K, WM, WN, NTW, 0, 0, 1>(a, smem, unused, unused,
+                                                    &w);
         pm_block_sync();
         own += w.store_n;
         left = 1;

@@ -237,8 +237,33 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
     a.TL = NC - 2 * a.halo;
     if (a.TL < 32) return hipErrorNotSupported;
     a.ntiles = (a.L + a.TL - 1) / a.TL;
-    auto kern = conv_block3_kernel<ET, C, K, WM, WN, NTW>;
     constexpr int smem = block3_smem_bytes<ET, C, K, WM, WN, NTW>();
+    // Walked variant (no left-halo recompute) for grids that fill the chip
+    // several times over, where its carry area (halo rows) fits the LDS
+    if constexpr (ET::ESZ == 2 && WM * WN == 8) {
+        const int smem_walk = block3_walk_smem_bytes<ET, C, K, WM, WN, NTW>() +
+                              block3_carry_bytes<ET, C>(a.halo);
+        int dev = 0, cus = 0;
+        if (a.niter <= 3 && smem_walk <= 160 * 1024 &&
+            hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
+                                  dev) == hipSuccess && cus > 0) {
+            int nseg = cus / a.B;
+            if (nseg < 1) nseg = 1;
+            if ((a.L / (NC - a.halo)) / nseg >= 8) {
+                Block3WalkArgs p;
+                p.a = a; p.nseg = nseg;
+                auto walk = conv_block3_walk_kernel<ET, C, K, WM, WN, NTW>;
+                hipError_t e = pm_ensure_dynamic_lds(
+                    reinterpret_cast<const void*>(walk), smem_walk);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(walk, dim3(a.B * nseg), dim3(WM * WN * 64),
+                                   smem_walk, stream, p);
+                return hipGetLastError();
+            }
+        }
+    }
+    auto kern = conv_block3_kernel<ET, C, K, WM, WN, NTW>;
     hipError_t e = pm_ensure_dynamic_lds(
         reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;
@@ -335,11 +360,9 @@ static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stre
                 wa.lengths = m.k[0].lengths; wa.len_scale = m.k[0].len_scale;
                 wa.nseg = nseg;
                 auto walk = conv_mrf_walk_kernel<ET, C, WM, WN, NTW>;
-                constexpr int smem_walk =
-                    block3_smem_bytes<ET, C, 11, WM, WN, NTW>() +
-                    block3_carry_bytes<ET, C, 11>(3) +
-                    block3_carry_bytes<ET, C, 7>(3) +
-                    block3_carry_bytes<ET, C, 3>(3);
+                const int smem_walk =
+                    block3_walk_smem_bytes<ET, C, 11, WM, WN, NTW>() +
+                    3 * block3_carry_bytes<ET, C>(halo);
                 hipError_t e = pm_ensure_dynamic_lds(
                     reinterpret_cast<const void*>(walk), smem_walk);
                 if (e != hipSuccess) return e;
