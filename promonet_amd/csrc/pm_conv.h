@@ -1001,7 +1001,8 @@ __host__ __device__ constexpr int block3_smem_bytes() {
 // request x again for the NEXT Block during the last iteration's epilogue 1,
 // into the conv1 accumulators (dead from there on), and hand it over in
 // `xnext`: the round trip runs under the last conv2 instead of in front of
-// the next Block's first conv.
+// the next Block's first conv. Walked kernels: bit 2 = the request is for the
+// NEXT tile (B3Walk::next_c_first), and bit 0 applies when B3Walk::have_x.
 // WALK (conv_mrf_walk_kernel): the workgroup walks consecutive tiles of one
 // utterance segment, left to right, and every layer's input keeps its last
 // columns in a small LDS "carry" area, from where the next tile fills its LEFT
@@ -1016,7 +1017,9 @@ struct B3Walk {
     int store_lo;     // first column this tile stores
     int store_n;      // columns it stores
     int left;         // 1: left margins come from the carry area
-    char* carry;      // this Block's carry area (niter x (MA + H2) rows)
+    int have_x;       // XMODE bit 0: `xnext` really holds this tile's x
+    int next_c_first; // XMODE bit 2: the tile whose x is requested, or < 0
+    char* carry;      // this Block's carry area (halo rows)
     // the Block's weight streams and dilations, read straight from the
     // kernel-argument segment (scalar loads with a run-time iteration index;
     // a by-value copy indexed at run time would live in scratch)
@@ -1147,7 +1150,9 @@ __device__ __forceinline__ void block3_body(
         max(min(L, c_first + NC) - x_lo, 0) * C * 4, 0x00020000);
     const unsigned xvoff0 = (unsigned)(
         ((c_first - x_lo + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
-    if constexpr (XMODE & 1) {
+    bool from_xnext = (XMODE & 1) != 0;
+    if constexpr (WALK && (XMODE & 1)) from_xnext = wk->have_x != 0;
+    if (from_xnext) {
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -1250,9 +1255,22 @@ __device__ __forceinline__ void block3_body(
                 store_tile_lrelu<ET>(tbuf + (H2 + col) * S, m_first + mt * 32,
                                      acc[mt][nt], t_tile, L, ln1, lh1);
                 if constexpr (XMODE & 2) {
-                    if (it + 1 == a.niter) {
+                    bool request = it + 1 == a.niter;
+                    if constexpr (WALK && (XMODE & 4))
+                        request = request && wk->next_c_first >= 0;
+                    if (request) {
+                        // the tile whose x is wanted: this one (the next
+                        // Block of an MRF launch) or the next of the walk
+                        int cf = c_first;
+                        if constexpr (WALK && (XMODE & 4)) cf = wk->next_c_first;
+                        const int lo = max(cf, 0);
+                        const __amdgpu_buffer_rsrc_t nrsrc =
+                            __builtin_amdgcn_make_buffer_rsrc(
+                                const_cast<float*>(xb) + (size_t)lo * C, 0,
+                                max(min(L, cf + NC) - lo, 0) * C * 4,
+                                0x00020000);
                         const unsigned xv = WALK
-                            ? (unsigned)(((c_first - x_lo + wn * NTW * 32 + ln1) *
+                            ? (unsigned)(((cf - lo + wn * NTW * 32 + ln1) *
                                           C + m_first + 4 * lh1) * 4)
                             : xvoff0;
                         const unsigned voff =
@@ -1261,7 +1279,7 @@ __device__ __forceinline__ void block3_body(
                         for (int g4 = 0; g4 < 4; ++g4) {
                             const pm_u4 v =
                                 __builtin_amdgcn_raw_buffer_load_b128(
-                                    xrsrc, voff + g4 * 32, 0, 0);
+                                    nrsrc, voff + g4 * 32, 0, 0);
                             acc[mt][nt][4 * g4 + 0] = __uint_as_float(v.x);
                             acc[mt][nt][4 * g4 + 1] = __uint_as_float(v.y);
                             acc[mt][nt][4 * g4 + 2] = __uint_as_float(v.z);
@@ -1560,16 +1578,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_walk_kernel(
         w.store_n = __builtin_amdgcn_readfirstlane(
             min(NC - H - w.store_lo, e0 - own));
         w.left = left;
+        // x: requested by the previous tile's last Block for this tile's
+        // first, by every Block for the next one of the same tile
+        const int next_own = own + w.store_n;
+        w.next_c_first = next_own < e0 ? next_own : -1;
+        w.have_x = left;
         block(w, 2, carry11);
-        block3_body<ET, C, 11, WM, WN, NTW, 1, 2, 1>(
+        block3_body<ET, C, 11, WM, WN, NTW, 1, 3, 1>(
             common, smem, sum, xnext, &w);
         pm_block_sync();
+        w.have_x = 1;
         block(w, 1, carry7);
         block3_body<ET, C, 7, WM, WN, NTW, 2, 3, 1>(
             common, smem, sum, xnext, &w);
         pm_block_sync();
         block(w, 0, carry3);
-        block3_body<ET, C, 3, WM, WN, NTW, 3, 1, 1>(
+        block3_body<ET, C, 3, WM, WN, NTW, 3, 7, 1>(
             common, smem, sum, xnext, &w);
         pm_block_sync();
         own += w.store_n;
@@ -1606,6 +1630,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_walk_kernel(
     w.carry = smem + block3_walk_smem_bytes<ET, C, K, WM, WN, NTW>();
     w.w1 = karg->a.w1; w.w2 = karg->a.w2; w.dil = karg->a.dil;
     floatx16 unused[(C / 32) / WM][NTW];
+    floatx16 xnext[(C / 32) / WM][NTW];
     int own = s0, left = 0;
 #pragma unroll 1
     while (own < e0) {
@@ -1616,7 +1641,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_walk_kernel(
         w.store_n = __builtin_amdgcn_readfirstlane(
             min(NC - H - w.store_lo, e0 - own));
         w.left = left;
-        block3_body<ET, C, K, WM, WN, NTW, 0, 0, 1>(a, smem, unused, unused,
+        // (x of the next tile is requested under this tile's last conv2)
+        const int next_own = own + w.store_n;
+        w.next_c_first = next_own < e0 ? next_own : -1;
+        w.have_x = left;
+        block3_body<ET, C, K, WM, WN, NTW, 0, 7, 1>(a, smem, unused, xnext,
                                                     &w);
         pm_block_sync();
         own += w.store_n;
