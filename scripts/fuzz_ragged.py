@@ -3,7 +3,8 @@ forward must equal the stand-alone synthesis of every utterance bit for bit
 (wide and narrow tile variants, every utterance-edge / tile-edge alignment the
 buffer-descriptor addressing has to get right), tails must be zero.
 usage: python scripts/fuzz_ragged.py [trials] [seed] [max batch]
-(batches of 20+ utterances of 100+ frames run the wide tile variants)"""
+(batches of 20+ utterances of 100+ frames run the wide tile variants; max
+batch <= 4 switches to long utterances, which run the walked kernels)"""
 import random
 import sys
 from pathlib import Path
@@ -34,7 +35,9 @@ for trial in range(trials):
     dtype = ('bf16', 'f16', 'fp32')[trial % 3]
     model = models[dtype]
     batch = rng.randint(max(1, max_batch // 2), max_batch)
-    top = rng.choice((3, 20, 60, 150, 300))
+    # (a few long utterances in a small batch: the walked kernels with many
+    # short, uneven segments against the stand-alone tiling of batch 1)
+    top = rng.choice((3, 20, 60, 150, 300) if max_batch > 4 else (900, 2500))
     lengths = [rng.randint(1, top) for _ in range(batch)]
     frames = max(lengths)
     inputs = [t.to(device) for t in
