@@ -518,6 +518,27 @@ def test_ragged_batch_is_exact(device, default_state):
     assert max_abs(ragged[3:4, :, :33 * 256], want) < GATE['f16']
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+def test_walked_kernels_match_standalone_tiling(device, default_state, dtype):
+    """A few long utterances in one batch run the walked whole-Block / MRF
+    kernels (one workgroup per utterance segment, left halo carried through
+    LDS); each utterance alone runs the stand-alone tiling. Same arithmetic per
+    column: bit-identical, tails zero."""
+    model = make_model(default_state, dtype, device)
+    lengths = [2300, 700, 1500]
+    frames = max(lengths)
+    inputs = on(device, oracle.synthetic_inputs(len(lengths), frames, seed=53))
+    with torch.inference_mode():
+        batched = model(*inputs, None, lengths=lengths)
+        for item, length in enumerate(lengths):
+            single = model(
+                *[t[item:item + 1, ..., :length] if t.ndim >= 2
+                  else t[item:item + 1] for t in inputs], None)
+            assert torch.equal(batched[item, :, :length * 256], single[0]), item
+            if length < frames:
+                assert batched[item, :, length * 256:].abs().max().item() == 0.
+
+
 def test_files_to_files_batched(device, default_state, tmp_path):
     """Batched file path == the reference-style sequential path, file by file."""
     import promonet_amd
