@@ -208,6 +208,10 @@ template <> struct Block3Cfg<ElemF16, 64, 3>   { enum { WM = 2, WN = 2, NTW = 4 
 template <> struct Block3Cfg<ElemF16, 64, 7>   { enum { WM = 2, WN = 4, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 64, 11>  { enum { WM = 2, WN = 4, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 2, NTW = 4 }; };
+// C = 128, k 7: walked only (conv_block3_walk_kernel; stand-alone, the 36-column
+// halo on both sides of a 256-column tile made it 28 % slower than three pair
+// launches - walked it is 10.6 % faster, profiles/r02/ab_block128_k7_walk.txt)
+template <> struct Block3Cfg<ElemF16, 128, 7>  { enum { WM = 4, WN = 2, NTW = 4 }; };
 template <int C, int K> struct Block3Cfg<ElemBF16, C, K> : Block3Cfg<ElemF16, C, K> {};
 template <> struct Block3Cfg<ElemF32, 32, 3>   { enum { WM = 1, WN = 8, NTW = 2 }; };
 template <> struct Block3Cfg<ElemF32, 32, 7>   { enum { WM = 1, WN = 8, NTW = 2 }; };
@@ -263,6 +267,7 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
             }
         }
     }
+    if constexpr (C == 128 && K == 7) return hipErrorNotSupported;  // walked only
     auto kern = conv_block3_kernel<ET, C, K, WM, WN, NTW>;
     hipError_t e = pm_ensure_dynamic_lds(
         reinterpret_cast<const void*>(kern), smem);
