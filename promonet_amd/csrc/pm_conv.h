@@ -1131,7 +1131,9 @@ __device__ __forceinline__ void block3_body(
                         reinterpret_cast<const float4*>(wk->carry)[i];
             }
         }
-        for (int i = tid; i < 2 * H2 * QS; i += NT) {
+        // (walked: no right margin behind `t` either - what lies behind it,
+        // the carry area, is finite and only reaches right-halo columns)
+        for (int i = tid; i < (WALK ? 1 : 2) * H2 * QS; i += NT) {
             const int r = i / QS, q = i % QS;
             const int row = r < H2 ? r : NC + r;
             *reinterpret_cast<float4*>(tbuf + row * S + q * 16) = z;
@@ -1512,7 +1514,7 @@ template <class ET, int C, int K, int WM, int WN, int NTW>
 __host__ __device__ constexpr int block3_walk_smem_bytes() {
     constexpr int NC = WN * NTW * 32;
     constexpr int S = C * ET::ESZ + 16;
-    return (NC + 5 * ((K - 1) / 2)) * S + (NC + (K - 1)) * S;
+    return (NC + 5 * ((K - 1) / 2)) * S + (NC + (K - 1) / 2) * S;
 }
 
 // (compact arguments: the three Blocks share everything but their weights
@@ -1561,6 +1563,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_walk_kernel(
         w.carry = carry;
         w.w1 = karg->w1[j]; w.w2 = karg->w2[j]; w.dil = karg->dil[j];
     };
+
+    for (int i = threadIdx.x; i < 3 * H * (C * ET::ESZ + 16) / 16;
+         i += WM * WN * 64)
+        reinterpret_cast<float4*>(carry11)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     floatx16 sum[(C / 32) / WM][NTW];
     floatx16 xnext[(C / 32) / WM][NTW];
@@ -1629,6 +1635,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_walk_kernel(
     w.L = L;
     w.carry = smem + block3_walk_smem_bytes<ET, C, K, WM, WN, NTW>();
     w.w1 = karg->a.w1; w.w2 = karg->a.w2; w.dil = karg->a.dil;
+    // (the carry area doubles as what the last taps of `t` read behind its
+    // last row: finite from the start)
+    for (int i = threadIdx.x; i < H * (C * ET::ESZ + 16) / 16; i += WM * WN * 64)
+        reinterpret_cast<float4*>(w.carry)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     floatx16 unused[(C / 32) / WM][NTW];
     floatx16 xnext[(C / 32) / WM][NTW];
     int own = s0, left = 0;

@@ -212,6 +212,8 @@ template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 2, NTW = 4 
 // halo on both sides of a 256-column tile made it 28 % slower than three pair
 // launches - walked it is 10.6 % faster, profiles/r02/ab_block128_k7_walk.txt)
 template <> struct Block3Cfg<ElemF16, 128, 7>  { enum { WM = 4, WN = 2, NTW = 4 }; };
+// (k 11 the same way - it fits 160 KB once `t` loses its right margin too - is
+// 7 % slower than three pair launches: 31 % more MFMA work)
 template <int C, int K> struct Block3Cfg<ElemBF16, C, K> : Block3Cfg<ElemF16, C, K> {};
 template <> struct Block3Cfg<ElemF32, 32, 3>   { enum { WM = 1, WN = 8, NTW = 2 }; };
 template <> struct Block3Cfg<ElemF32, 32, 7>   { enum { WM = 1, WN = 8, NTW = 2 }; };
