@@ -212,6 +212,10 @@ template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 2, NTW = 4 
 // halo on both sides of a 256-column tile made it 28 % slower than three pair
 // launches - walked it is 10.6 % faster, profiles/r02/ab_block128_k7_walk.txt)
 template <> struct Block3Cfg<ElemF16, 128, 7>  { enum { WM = 4, WN = 2, NTW = 4 }; };
+// C = 256, k 3: walked only, 128-column tiles (12 of them halo): 0.67 -> 0.53 ms
+// against three pair launches (profiles/r02/ab_block256_walk.txt)
+template <> struct Block3Cfg<ElemF16, 256, 3>  { enum { WM = 8, WN = 1, NTW = 4 }; };
+// (k 7 the same way: 36 of 128 columns halo, 1.45 vs 1.19 ms - stays on the pair kernel)
 // (k 11 the same way - it fits 160 KB once `t` loses its right margin too - is
 // 7 % slower than three pair launches: 31 % more MFMA work)
 template <int C, int K> struct Block3Cfg<ElemBF16, C, K> : Block3Cfg<ElemF16, C, K> {};
@@ -256,7 +260,7 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
                                   dev) == hipSuccess && cus > 0) {
             int nseg = cus / a.B;
             if (nseg < 1) nseg = 1;
-            if ((a.L / (NC - a.halo)) / nseg >= 8) {
+            if ((a.L / (NC - a.halo)) / nseg >= 6) {
                 Block3WalkArgs p;
                 p.a = a; p.nseg = nseg;
                 auto walk = conv_block3_walk_kernel<ET, C, K, WM, WN, NTW>;
@@ -269,7 +273,8 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
             }
         }
     }
-    if constexpr (C == 128 && K == 7) return hipErrorNotSupported;  // walked only
+    if constexpr ((C == 128 && K == 7) || C == 256)
+        return hipErrorNotSupported;  // walked only
     auto kern = conv_block3_kernel<ET, C, K, WM, WN, NTW>;
     hipError_t e = pm_ensure_dynamic_lds(
         reinterpret_cast<const void*>(kern), smem);
@@ -437,6 +442,7 @@ static bool block3_supported_c(int K) {
 template <class ET>
 bool pm_block3_supported(int C, int K) {
     switch (C) {
+        case 256: return block3_supported_c<ET, 256>(K);
         case 128: return block3_supported_c<ET, 128>(K);
         case 64: return block3_supported_c<ET, 64>(K);
         case 32: return block3_supported_c<ET, 32>(K);
@@ -450,6 +456,7 @@ hipError_t pm_launch_block3(int C, int K, const Block3Args& a, hipStream_t s) {
         if (a.dil[i] < 1 || a.dil[i] > 5) return hipErrorNotSupported;
     if (a.niter < 1 || a.niter > 3) return hipErrorNotSupported;
     switch (C) {
+        case 256: return launch_block3_c<ET, 256>(K, a, s);
         case 128: return launch_block3_c<ET, 128>(K, a, s);
         case 64: return launch_block3_c<ET, 64>(K, a, s);
         case 32: return launch_block3_c<ET, 32>(K, a, s);
