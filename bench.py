@@ -198,8 +198,9 @@ def parse_profile(text):
 def main():
     args = parse_args()
     if args.dtype is None:
-        args.dtype = 'fp32' if args.model == 'fargan' else \
-            promonet_amd.config.DEFAULT_COMPUTE_DTYPE
+        # (bf16: what BASELINE.json's batch-32 x 10 s config names; the
+        # library's own default is f16, promonet_amd/config.py)
+        args.dtype = 'fp32' if args.model == 'fargan' else 'bf16'
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
     rank, world, device = promonet_amd.distributed.init()

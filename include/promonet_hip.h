@@ -65,6 +65,11 @@ typedef struct pm_hifigan_config {
     int num_dilations;
     int resblock_dilations[PM_MAX_RESBLOCKS][PM_MAX_DILATIONS];
     int compute_dtype;                /* PM_F32 | PM_F16 | PM_BF16         */
+    /* Per-stage override of the MFMA operand type (upsampler + MRF of stage
+     * i): 0 = compute_dtype, else 1 + PM_F32 | PM_F16 | PM_BF16. E.g. bf16
+     * for the wide stages and f16 for the last two, whose rounding reaches
+     * the output most directly.                                           */
+    int stage_compute_dtype[PM_MAX_STAGES];
 } pm_hifigan_config;
 
 int pm_version(void);
@@ -237,6 +242,12 @@ int pm_out_conv_tanh(const float* x_cl, const float* w, float* out,
 /* Debug instrumentation: per-workgroup phase timestamps (s_memtime) of the
  * following fused-conv launches; buffer of 8 uint64 per workgroup or NULL  */
 int pm_debug_timeline(void* dev_buffer);
+/* Test hook: the walked (carry-through-LDS) variants of pm_block_cl /
+ * pm_mrf_cl / the engine and the multi-block path of the wide upsampler are
+ * chosen from the grid size; walk_nseg > 0 forces the walked variant with
+ * that many segments per utterance, upsample_groups > 0 that many M groups
+ * per column tile; 0, 0 restores the heuristics. Process-wide.             */
+int pm_debug_force(int walk_nseg, int upsample_groups);
 /* torch.nn.utils.weight_norm fold: w = g * v / ||v||, rows x cols        */
 int pm_fold_weight_norm(const float* g, const float* v, float* w, int rows,
                         int cols, void* stream);
@@ -310,9 +321,32 @@ int pm_fargan_check(pm_fargan_t h, int batch, int frames, void* workspace,
 /* spectrogram.from_audio (spectrogram.py:15-60): reflect-pad 384, hann-1024
  * hop-256 framed DFT, sqrt(re^2 + im^2 + 1e-6): audio (B, N) ->
  * (B, 513, N / 256)                                                       */
+/* (a 1024-point real FFT per frame in LDS; `scratch` is unused by it and may
+ * be NULL - the argument stays for the ABI of rounds 1-2)                  */
 size_t pm_stft_scratch_bytes(int batch, int samples);
 int pm_stft_magnitude(const float* audio, float* out, int batch, int samples,
                       void* scratch, size_t scratch_bytes, void* stream);
+/* The same spectrogram by the brute-force framed-DFT GEMM (exact-fp32 MFMA):
+ * an independent cross-check of the FFT; scratch: pm_stft_scratch_bytes()  */
+int pm_stft_magnitude_dft(const float* audio, float* out, int batch,
+                          int samples, void* scratch, size_t scratch_bytes,
+                          void* stream);
+/* spectrogram.from_audio(audio, mels=True) (spectrogram.py:56-58 ->
+ * linear_to_mel :111-133) in one kernel: log(basis @ magnitude), optional
+ * clamp, straight from the FFT workgroup's LDS tile: audio (B, N) ->
+ * (B, mels, N / 256). pm_stft_mel_prepare compacts the (mels, 513) basis
+ * (librosa.filters.mel at spectrogram.py:118-121) into `prepared`
+ * (pm_stft_mel_scratch_bytes(mels) bytes) once; the reference rebuilds its
+ * basis on every call.                                                      */
+size_t pm_stft_mel_scratch_bytes(int mels);
+int pm_stft_mel_prepare(const float* basis, int mels, void* prepared,
+                        size_t prepared_bytes, void* stream);
+int pm_stft_mel(const float* audio, const void* prepared, float* out,
+                int batch, int samples, int mels, int use_threshold,
+                float log_threshold, void* stream);
+/* Tuning knob: frames per FFT workgroup, 16 (default; two workgroups per CU)
+ * or 32 (one 8-wave workgroup, 128-byte output rows)                       */
+int pm_stft_set_frames_per_group(int frames);
 /* spectrogram.linear_to_mel (spectrogram.py:111-133): log(basis @ spec),
  * optional clamp: spec (B, F, T), basis (Mel, F) -> (B, Mel, T)           */
 int pm_linear_to_mel(const float* spec, const float* basis, float* out,
@@ -336,6 +370,7 @@ int pm_linear_to_mel_backward(const float* spec, const float* basis,
 /* loudness.from_audio (loudness.py:17-55) per utterance: A-weighted dB with
  * the utterance-global (max - 80 dB) floor of librosa.amplitude_to_db, then
  * band_average (loudness.py:84-111): audio (B, N) -> (B, bands, N / 256);
+ * two FFT passes over the audio (maximum, then bands), no dB tensor in HBM;
  * a_weights (513) = perceptual_weights() (loudness.py:149-160);
  * scratch: pm_loudness_scratch_bytes()                                     */
 size_t pm_loudness_scratch_bytes(int batch, int samples);

@@ -33,7 +33,8 @@ class HifiganConfig(ctypes.Structure):
         ('resblock_kernel_sizes', ctypes.c_int * MAX_RESBLOCKS),
         ('num_dilations', ctypes.c_int),
         ('resblock_dilations', (ctypes.c_int * MAX_DILATIONS) * MAX_RESBLOCKS),
-        ('compute_dtype', ctypes.c_int)]
+        ('compute_dtype', ctypes.c_int),
+        ('stage_compute_dtype', ctypes.c_int * MAX_STAGES)]
 
 
 # name -> (restype, argtypes); every symbol include/promonet_hip.h declares
@@ -67,6 +68,7 @@ SIGNATURES = {
     'pm_conv_transpose_cl': (_I, [_I] + [_P] * 4 + [_I] * 6 + [_P, _S, _P]),
     'pm_out_conv_tanh': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'pm_debug_timeline': (_I, [_P]),
+    'pm_debug_force': (_I, [_I, _I]),
     'pm_fold_weight_norm': (_I, [_P, _P, _P, _I, _I, _P]),
     'pm_to_channels_last': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'pm_grid_sample': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _P]),
@@ -82,6 +84,11 @@ SIGNATURES = {
     'pm_fargan_check': (_I, [_P, _I, _I, _P, _P]),
     'pm_stft_scratch_bytes': (_S, [_I, _I]),
     'pm_stft_magnitude': (_I, [_P, _P, _I, _I, _P, _S, _P]),
+    'pm_stft_magnitude_dft': (_I, [_P, _P, _I, _I, _P, _S, _P]),
+    'pm_stft_mel_scratch_bytes': (_S, [_I]),
+    'pm_stft_mel_prepare': (_I, [_P, _I, _P, _S, _P]),
+    'pm_stft_mel': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    'pm_stft_set_frames_per_group': (_I, [_I]),
     'pm_linear_to_mel': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'pm_stft_backward_scratch_bytes': (_S, [_I, _I]),
     'pm_stft_magnitude_backward': (_I, [_P, _P, _P, _I, _I, _P, _S, _P]),

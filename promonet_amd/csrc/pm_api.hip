@@ -1,7 +1,7 @@
 // C ABI of libpromonet_hip.so (see include/promonet_hip.h) and the HiFi-GAN
 // engine behind it: weight folding / packing at load, workspace planning and
 // the per-forward launch sequence. Host C++; every kernel it launches is
-// hand-written HIP for gfx950 (pm_conv.h, pm_misc.h, pm_stft.h).
+// hand-written HIP for gfx950 (pm_conv.h, pm_misc.h, pm_stft.h, pm_fft.h).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -17,6 +17,7 @@
 #include "pm_launch.h"
 #include "pm_misc.h"
 #include "pm_stft.h"
+#include "pm_fft.h"
 #include "pm_fargan.h"
 
 #define PM_VERSION 100
@@ -253,10 +254,12 @@ struct Layer {
     float* tmp_v = nullptr;
     bool has_w = false, has_b = false;
     int cfg = 0;
+    int dtype = PM_F16;       // MFMA operand type this layer is packed for
 };
 
 struct Stage {
     int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0, r = 0, k = 0;
+    int dtype = PM_F16;       // operand type of the stage (upsampler + MRF)
     Layer up;
     Layer c1[PM_MAX_RESBLOCKS][PM_MAX_DILATIONS];
     Layer c2[PM_MAX_RESBLOCKS][PM_MAX_DILATIONS];
@@ -341,9 +344,14 @@ extern "C" int pm_hifigan_create(
                 return fail(PM_EINVAL, "dilation %d unsupported (1..5)", d);
         }
     }
+    for (int i = 0; i < c->num_stages; ++i)
+        if (c->stage_compute_dtype[i] < 0 || c->stage_compute_dtype[i] > 3)
+            return fail(PM_EINVAL, "stage_compute_dtype[%d] = %d unknown", i,
+                        c->stage_compute_dtype[i]);
     auto* h = new pm_hifigan_s();
     h->cfg = *c;
     h->dtype = c->compute_dtype;
+    h->in_conv.dtype = h->dtype;
     h->cfp = pad32(c->num_features);
     h->c0 = c->initial_channels;
     h->c0p = pad32(h->c0);
@@ -353,6 +361,9 @@ extern "C" int pm_hifigan_create(
         Stage& s = h->stages[i];
         s.r = c->upsample_rates[i];
         s.k = c->upsample_kernel_sizes[i];
+        s.dtype = c->stage_compute_dtype[i] ? c->stage_compute_dtype[i] - 1
+                                            : h->dtype;
+        s.up.dtype = s.dtype;
         if (s.r < 2 || (s.r & 1) || s.k != 2 * s.r) {
             delete h;
             return fail(PM_EINVAL,
@@ -378,18 +389,19 @@ extern "C" int pm_hifigan_create(
         g.cout_pad = s.cout_pad; g.cin_pad = s.cin_pad;
         g.M = s.r * s.cout_pad; g.kt = 2; g.r = s.r; g.p = s.r / 2;
         g.ch = (s.cin_pad % 64 == 0) ? 64 : 32;
-        s.up.cfg = upsample_whole_k(h->dtype, g)
+        s.up.cfg = upsample_whole_k(s.dtype, g)
             ? 4
             : single_cfg(g.M, g.ch, ((s.r / 2) * s.cout_pad) % 64 == 0);
         for (int j = 0; j < c->num_resblocks; ++j)
             for (int n = 0; n < c->num_dilations; ++n)
                 for (int which = 0; which < 2; ++which) {
+                    (which ? s.c2 : s.c1)[j][n].dtype = s.dtype;
                     ConvGeom& q = (which ? s.c2 : s.c1)[j][n].geom;
                     q.mode = 0; q.cout = q.cin = s.cout;
                     q.k = c->resblock_kernel_sizes[j];
                     q.cout_pad = q.cin_pad = q.M = s.cout_pad;
                     q.kt = q.k;
-                    q.ch = mrf_chunk(h->dtype, s.cout_pad, q.k, c->num_dilations);
+                    q.ch = mrf_chunk(s.dtype, s.cout_pad, q.k, c->num_dilations);
                     q.bias_step = true;
                 }
     }
@@ -452,12 +464,12 @@ static int set_weight(
     if (ndim != 3 || shape[0] != d0 || shape[1] != d1 || shape[2] != g.k)
         return fail(PM_EINVAL, "%s: expected shape (%lld, %lld, %d)", name,
                     (long long)d0, (long long)d1, g.k);
-    const size_t bytes = g.packed_elems() * esz(h->dtype);
+    const size_t bytes = g.packed_elems() * esz(l.dtype);
     if (!l.w) HIP_TRY(hipMalloc(&l.w, bytes));
-    HIP_TRY(pack_weights(h->dtype, g, w, l.w, s));
+    HIP_TRY(pack_weights(l.dtype, g, w, l.w, s));
     l.has_w = true;
     if (g.bias_step && l.has_b)
-        HIP_TRY(pack_bias_step(h->dtype, g, l.bias, l.w, s));
+        HIP_TRY(pack_bias_step(l.dtype, g, l.bias, l.w, s));
     return PM_OK;
 }
 
@@ -474,7 +486,7 @@ static int set_bias(
     HIP_TRY(pad_bias(b, l.bias, g.cout, g.cout_pad, rep, s));
     l.has_b = true;
     if (g.bias_step && l.has_w)
-        HIP_TRY(pack_bias_step(h->dtype, g, l.bias, l.w, s));
+        HIP_TRY(pack_bias_step(l.dtype, g, l.bias, l.w, s));
     return PM_OK;
 }
 
@@ -685,7 +697,7 @@ static int forward_impl(
         PROF(h, s, "input_conv",
              2.0 * h->c0 * h->cfg.num_features * 7 * B * T,
              (double)B * T * (h->cfg.num_features + h->c0) * 4, {
-            HIP_TRY(launch_single(h->dtype, 0, h->in_conv.geom.ch,
+            HIP_TRY(launch_single(h->in_conv.dtype, 0, h->in_conv.geom.ch,
                                   h->in_conv.cfg, a, s));
         });
     }
@@ -707,7 +719,7 @@ static int forward_impl(
             snprintf(label, sizeof(label), "convT_c%d_r%d", st.cin, st.r);
             PROF(h, s, label, 2.0 * st.cin * st.cout * st.k * B * L,
                  (double)B * L * (st.cin + (double)st.r * st.cout) * 4, {
-                HIP_TRY(launch_single(h->dtype, 1, st.up.geom.ch, st.up.cfg,
+                HIP_TRY(launch_single(st.dtype, 1, st.up.geom.ch, st.up.cfg,
                                       a, s));
             });
         }
@@ -741,7 +753,7 @@ static int forward_impl(
             snprintf(label, sizeof(label), "mrf_c%d", st.cout);
             hipError_t e = hipSuccess;
             PROF(h, s, label, flops, (double)B * L * st.cout * 4 * 2, {
-                e = launch_mrf(h->dtype, st.cout_pad, blocks, s);
+                e = launch_mrf(st.dtype, st.cout_pad, blocks, s);
                 if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
             });
             mrf_done = e == hipSuccess;
@@ -751,7 +763,7 @@ static int forward_impl(
             const int K = h->cfg.resblock_kernel_sizes[j];
             bool fused = false;
             if (h->cfg.num_dilations <= 3 &&
-                block3_supported(h->dtype, st.cout_pad, K)) {
+                block3_supported(st.dtype, st.cout_pad, K)) {
                 // whole Block (all dilations) in one kernel: U -> S
                 Block3Args a = {};
                 a.x = buf[ui]; a.out = buf[si];
@@ -770,7 +782,7 @@ static int forward_impl(
                 hipError_t e = hipSuccess;
                 PROF(h, s, label, flops,
                      (double)B * L * st.cout * 4 * (a.mode == 2 ? 3 : 2), {
-                    e = launch_block3(h->dtype, st.cout_pad, K, a, s);
+                    e = launch_block3(st.dtype, st.cout_pad, K, a, s);
                     if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
                 });
                 fused = e == hipSuccess;
@@ -794,7 +806,7 @@ static int forward_impl(
                 snprintf(label, sizeof(label), "pair_c%d_k%d", st.cout, K);
                 PROF(h, s, label, 4.0 * st.cout * st.cout * K * B * L,
                      (double)B * L * st.cout * 4 * (a.mode == 2 ? 3 : 2), {
-                    HIP_TRY(launch_pair(h->dtype, st.cout_pad, K, a, s));
+                    HIP_TRY(launch_pair(st.dtype, st.cout_pad, K, a, s));
                 });
                 src = dst;
             }
@@ -1053,7 +1065,7 @@ extern "C" int pm_block_cl(
     if (!x || !out || !w1 || !b1 || !w2 || !b2 || !dilations || !ws)
         return fail(PM_EINVAL, "null argument");
     const int Cp = pad32(C);
-    if (Cp > 128) return fail(PM_EINVAL, "channels %d unsupported (<= 128)", C);
+    if (Cp > 256) return fail(PM_EINVAL, "channels %d unsupported (<= 256)", C);
     if ((K != 3 && K != 7 && K != 11) || niter < 1 || niter > 3)
         return fail(PM_EINVAL, "kernel %d / %d iterations unsupported", K, niter);
     if (ws_bytes < 3 * pm_op_workspace_bytes(C, C, K))
@@ -1231,6 +1243,18 @@ extern "C" int pm_out_conv_tanh(
     return PM_OK;
 }
 
+// Test hook: force the walked whole-Block / whole-MRF kernels (with
+// `walk_nseg` segments per utterance) and the number of M groups of the wide
+// upsampler, which the launchers otherwise pick from the grid size - so that
+// unit-sized inputs reach those code paths. 0 restores the heuristics.
+extern "C" int pm_debug_force(int walk_nseg, int upsample_groups) {
+    if (walk_nseg < 0 || upsample_groups < 0)
+        return fail(PM_EINVAL, "negative value");
+    pm_force().walk_nseg = walk_nseg;
+    pm_force().upsample_groups = upsample_groups;
+    return PM_OK;
+}
+
 extern "C" int pm_fold_weight_norm(
     const float* g, const float* v, float* w, int rows, int cols,
     void* stream) {
@@ -1346,11 +1370,136 @@ static int stft_launch(
     return PM_OK;
 }
 
-extern "C" int pm_stft_magnitude(
+// Brute-force cross-check of pm_stft_magnitude: the same spectrogram by the
+// framed-DFT GEMM (exact-fp32 MFMA), independent of the FFT code path.
+extern "C" int pm_stft_magnitude_dft(
     const float* audio, float* out, int B, int N, void* scratch,
     size_t scratch_bytes, void* stream) {
     return stft_launch(1, audio, out, nullptr, B, N, scratch, scratch_bytes,
                        (hipStream_t)stream);
+}
+
+// ---- FFT path (forward transforms; pm_fft.h) --------------------------------
+static std::map<int, float*> g_fft_tables;   // per device (g_basis_mutex)
+static int g_fft_frames_per_group = 16;
+
+static int get_fft_tables(const float** out, hipStream_t s) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_basis_mutex);
+    auto it = g_fft_tables.find(dev);
+    if (it != g_fft_tables.end()) { *out = it->second; return PM_OK; }
+    std::vector<float> h(PM_FFT_TAB_FLOATS);
+    const double pi2 = 6.283185307179586476925286766559;
+    // periodic hann (torch.hann_window(1024), spectrogram.py:29)
+    for (int n = 0; n < NFFT; ++n)
+        h[n] = (float)(0.5 - 0.5 * cos(pi2 * n / NFFT));
+    for (int j = 0; j < 512; ++j) {
+        h[PM_FFT_TAB_W512 + 2 * j] = (float)cos(pi2 * j / 512.0);
+        h[PM_FFT_TAB_W512 + 2 * j + 1] = (float)-sin(pi2 * j / 512.0);
+    }
+    for (int k = 0; k <= 512; ++k) {
+        h[PM_FFT_TAB_W1024 + 2 * k] = (float)cos(pi2 * k / 1024.0);
+        h[PM_FFT_TAB_W1024 + 2 * k + 1] = (float)-sin(pi2 * k / 1024.0);
+    }
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(d, h.data(), h.size() * sizeof(float),
+                           hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    g_fft_tables[dev] = d;
+    *out = d;
+    return PM_OK;
+}
+
+extern "C" int pm_stft_set_frames_per_group(int frames) {
+    if (frames != 16 && frames != 32)
+        return fail(PM_EINVAL, "frames per workgroup must be 16 or 32");
+    g_fft_frames_per_group = frames;
+    return PM_OK;
+}
+
+template <int EPI>
+static int fft_launch(FftArgs& a, hipStream_t s) {
+    const int pad = (NFFT - HOP) / 2;
+    if (!a.audio) return fail(PM_EINVAL, "null argument");
+    if (a.B < 1 || a.N <= pad)
+        return fail(PM_EINVAL, "need more than %d samples (reflect pad)", pad);
+    a.T = a.N / HOP;
+    if (a.T < 1) return fail(PM_EINVAL, "fewer samples than one hop");
+    if (a.B > 65535) return fail(PM_EINVAL, "batch too large (max 65535)");
+    int rc = get_fft_tables(&a.tables, s);
+    if (rc) return rc;
+    if (g_fft_frames_per_group == 32) {
+        auto kern = pm_stft_fft_kernel<EPI, 8, 4>;
+        constexpr int smem = pm_fft_smem_bytes<EPI, 8, 4>();
+        HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
+        hipLaunchKernelGGL(kern, dim3((a.T + 31) / 32, a.B), dim3(512), smem,
+                           s, a);
+    } else {
+        auto kern = pm_stft_fft_kernel<EPI, 4, 4>;
+        constexpr int smem = pm_fft_smem_bytes<EPI, 4, 4>();
+        HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
+        hipLaunchKernelGGL(kern, dim3((a.T + 15) / 16, a.B), dim3(256), smem,
+                           s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" int pm_stft_magnitude(
+    const float* audio, float* out, int B, int N, void* scratch,
+    size_t scratch_bytes, void* stream) {
+    (void)scratch; (void)scratch_bytes;   // (the FFT path needs none)
+    if (!out) return fail(PM_EINVAL, "null argument");
+    FftArgs a = {};
+    a.audio = audio; a.out = out; a.B = B; a.N = N;
+    return fft_launch<1>(a, (hipStream_t)stream);
+}
+
+// spectrogram.from_audio(audio, mels=True): the log-mel spectrogram straight
+// from the FFT workgroup's LDS tile (the (B, 513, T) magnitudes never reach
+// HBM). basis (mels, 513) -> pm_stft_mel_prepare -> `prepared`
+// (pm_stft_mel_scratch_bytes(mels) bytes, reusable)
+extern "C" size_t pm_stft_mel_scratch_bytes(int mels) {
+    return mels < 1 ? 0 : align256((size_t)(3 * mels + 1) * sizeof(int)) +
+                              align256((size_t)mels * BINS * sizeof(float));
+}
+
+// Compact the (mels, 513) filterbank once (per basis): `prepared` then feeds
+// any number of pm_stft_mel calls.
+extern "C" int pm_stft_mel_prepare(
+    const float* basis, int mels, void* prepared, size_t prepared_bytes,
+    void* stream) {
+    if (!basis || !prepared) return fail(PM_EINVAL, "null argument");
+    if (mels < 1 || mels > 1024)
+        return fail(PM_EINVAL, "1..1024 mel filters");
+    if (prepared_bytes < pm_stft_mel_scratch_bytes(mels))
+        return fail(PM_ENOMEM, "buffer too small");
+    int* table = (int*)prepared;
+    float* vals = (float*)((char*)prepared +
+                           align256((size_t)(3 * mels + 1) * sizeof(int)));
+    hipLaunchKernelGGL(pm_mel_csr_kernel, dim3(1), dim3(256), 0,
+                       (hipStream_t)stream, basis, table, vals, mels, BINS);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" int pm_stft_mel(
+    const float* audio, const void* prepared, float* out, int B, int N,
+    int mels, int use_threshold, float log_threshold, void* stream) {
+    if (!prepared || !out) return fail(PM_EINVAL, "null argument");
+    if (mels < 1 || mels > 1024)
+        return fail(PM_EINVAL, "1..1024 mel filters");
+    hipStream_t s = (hipStream_t)stream;
+    const int* table = (const int*)prepared;
+    const float* vals = (const float*)((const char*)prepared +
+                           align256((size_t)(3 * mels + 1) * sizeof(int)));
+    FftArgs a = {};
+    a.audio = audio; a.out = out; a.B = B; a.N = N;
+    a.mel_span = table; a.mel_vals = vals; a.rows = mels;
+    a.use_thr = use_threshold; a.thr = log_threshold;
+    return fft_launch<4>(a, s);
 }
 
 // Backward of pm_stft_magnitude (the training mel loss differentiates through
@@ -1435,11 +1584,13 @@ extern "C" int pm_linear_to_mel(
 
 extern "C" size_t pm_loudness_scratch_bytes(int B, int N) {
     if (B < 1 || N < HOP) return 0;
-    const size_t T = N / HOP;
-    return pm_stft_scratch_bytes(B, N) +
-           align256((size_t)B * BINS * T * sizeof(float)) + align256(B * 4);
+    return align256((size_t)B * sizeof(unsigned));
 }
 
+// Two passes over the audio (4 B / sample each) instead of a (B, 513, T) dB
+// tensor written and re-read: pass 1 finds every utterance's maximum dB
+// (librosa.amplitude_to_db's top_db reference, loudness.py:46), pass 2 repeats
+// the FFT and writes the floored, A-weighted band means.
 extern "C" int pm_loudness(
     const float* audio, const float* a_weights, float* out, int B, int N,
     int bands, float min_db, void* scratch, size_t scratch_bytes,
@@ -1448,30 +1599,22 @@ extern "C" int pm_loudness(
         return fail(PM_EINVAL, "null argument");
     if (bands < 1 || (bands > 16 && bands != BINS))
         return fail(PM_EINVAL, "bands must be 1..16 or 513 (no averaging)");
-    if (scratch_bytes < pm_loudness_scratch_bytes(B, N) || N < HOP)
+    if (B < 1 || N < HOP || scratch_bytes < pm_loudness_scratch_bytes(B, N))
         return fail(PM_ENOMEM, "scratch too small");
     hipStream_t s = (hipStream_t)stream;
-    const int T = N / HOP;
-    char* base = (char*)scratch;
-    const size_t stft_bytes = pm_stft_scratch_bytes(B, N);
-    float* db = (float*)(base + stft_bytes);
-    unsigned* maxbits = (unsigned*)(base + stft_bytes +
-                                    align256((size_t)B * BINS * T * sizeof(float)));
+    unsigned* maxbits = (unsigned*)scratch;
     HIP_TRY(hipMemsetAsync(maxbits, 0, B * sizeof(unsigned), s));
-    int rc = stft_launch(2, audio, db, maxbits, B, N, base, stft_bytes, s);
+    FftArgs a = {};
+    a.audio = audio; a.out = out; a.B = B; a.N = N; a.maxbits = maxbits;
+    int rc = fft_launch<2>(a, s);
     if (rc) return rc;
-    LoudnessArgs a;
-    a.db = db; a.maxbits = maxbits; a.weights = a_weights; a.out = out;
-    a.F = BINS; a.T = T; a.bands = bands;
+    a.weights = a_weights; a.rows = bands;
     const double step = (double)BINS / (double)bands;   // loudness.py:96
     for (int b = 0; b <= bands && b <= 16; ++b)
         a.band_start[b] = (int)(b * step);
     if (bands == 1) { a.band_start[0] = 0; a.band_start[1] = BINS; }
     a.min_db = min_db; a.top_db = 80.f;
-    hipLaunchKernelGGL(pm_loudness_bands_kernel, dim3((T + 255) / 256, bands, B),
-                       dim3(256), 0, s, a);
-    HIP_TRY(hipGetLastError());
-    return PM_OK;
+    return fft_launch<3>(a, s);
 }
 
 // promonet.edit feature editing (edit/core.py:17-132, edit/grid.py:12-45)

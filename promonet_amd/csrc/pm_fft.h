@@ -1,0 +1,362 @@
+// Framed STFT as a real FFT in LDS (round 3; the framed-DFT GEMM of pm_stft.h
+// stays for the backward pass only).
+// Reference: promonet/preprocess/spectrogram.py:15-60 (torch.stft of the
+// reflect-padded audio, hann-1024, hop 256, sqrt(re^2 + im^2 + 1e-6)),
+// promonet/preprocess/loudness.py:17-55 (librosa.stft, amplitude_to_db with
+// top_db 80, A-weighting, band_average) and spectrogram.py:111-133 (log-mel).
+//
+// One wave = one frame at a time: the 1024 windowed real samples are packed
+// into 512 complex points z[n] = x[2n] + i x[2n + 1], transformed by a
+// 512-point complex FFT (three radix-8 stages, 8 points per lane in registers,
+// two wave-private exchanges through LDS), and unpacked into the 513 bins of
+// the real transform. A workgroup owns FR consecutive frames of one utterance:
+// every wave loads its frame's samples straight into registers (coalesced
+// 512-byte rows, the next frame requested before the current one is
+// transformed; the 4x overlap of neighbouring frames is served by L1 / L2, the
+// reflect padding is resolved on the fly in the two edge frames), and the
+// 513 x FR results are transposed through LDS so that the (B, 513, T)
+// spectrogram is written in rows of FR consecutive frames.
+// HBM traffic = the algorithmic 4 B / sample in + 2052 B / frame out
+// (the GEMM formulation did 40x the FLOPs: 57.9 GFLOP of dense DFT against
+// ~1.4 GFLOP of FFT at batch 32 x 10 s).
+//
+// EPI 1: magnitude (B, 513, T)                         spectrogram.py:53
+// EPI 2: utterance maximum of 10 log10(max(1e-10, |X|^2)) only (no output)
+// EPI 3: A-weighted, floored dB, band means (B, bands, T)   loudness.py:46-55,84-111
+// EPI 4: log-mel (B, mels, T)                           spectrogram.py:111-133
+#pragma once
+#include "pm_common.h"
+
+#define PM_FFT_N 1024
+#define PM_FFT_HOP 256
+#define PM_FFT_BINS 513
+#define PM_FFT_PAD 384
+// table layout (floats): hann[1024] | W512^j (re, im) j < 512 | W1024^k k <= 512
+#define PM_FFT_TAB_W512 1024
+#define PM_FFT_TAB_W1024 (1024 + 1024)
+#define PM_FFT_TAB_FLOATS (1024 + 1024 + 1026)
+
+struct FftArgs {
+    const float* audio;      // (B, N)
+    float* out;
+    const float* tables;     // PM_FFT_TAB_FLOATS
+    unsigned* maxbits;       // (B) order-preserving bits of the utterance max
+    const float* weights;    // EPI 3: (513) A-weights; EPI 4: mel basis (M, 513)
+    const int* mel_span;     // EPI 4: pm_mel_csr_kernel's table (lo, hi, offset
+                             // per filter, then the non-zero count)
+    const float* mel_vals;   // EPI 4: the filters' non-zero spans, compacted
+    int B, N, T;
+    int rows;                // EPI 3: bands; EPI 4: mels
+    int band_start[17];
+    float min_db, top_db;    // EPI 3
+    int use_thr; float thr;  // EPI 4
+};
+
+__device__ __forceinline__ float2 pm_cadd(float2 a, float2 b) {
+    return make_float2(a.x + b.x, a.y + b.y);
+}
+__device__ __forceinline__ float2 pm_csub(float2 a, float2 b) {
+    return make_float2(a.x - b.x, a.y - b.y);
+}
+__device__ __forceinline__ float2 pm_cmul(float2 a, float2 w) {
+    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+
+// 4-point DFT (W4 = -i): o[r] = sum_n c[n] (-i)^(n r)
+__device__ __forceinline__ void pm_dft4(
+    float2 c0, float2 c1, float2 c2, float2 c3, float2& o0, float2& o1,
+    float2& o2, float2& o3) {
+    const float2 d0 = pm_cadd(c0, c2), d1 = pm_csub(c0, c2);
+    const float2 d2 = pm_cadd(c1, c3), e = pm_csub(c1, c3);
+    const float2 d3 = make_float2(e.y, -e.x);       // -i (c1 - c3)
+    o0 = pm_cadd(d0, d2); o1 = pm_cadd(d1, d3);
+    o2 = pm_csub(d0, d2); o3 = pm_csub(d1, d3);
+}
+
+// In-place 8-point DFT, a[k] <- sum_n a[n] W8^(n k), W8 = exp(-2 pi i / 8)
+__device__ __forceinline__ void pm_radix8(float2 (&a)[8]) {
+    const float h = 0.70710678118654752440f;
+    const float2 b0 = pm_cadd(a[0], a[4]), b4 = pm_csub(a[0], a[4]);
+    const float2 b1 = pm_cadd(a[1], a[5]), e5 = pm_csub(a[1], a[5]);
+    const float2 b2 = pm_cadd(a[2], a[6]), e6 = pm_csub(a[2], a[6]);
+    const float2 b3 = pm_cadd(a[3], a[7]), e7 = pm_csub(a[3], a[7]);
+    const float2 b5 = make_float2((e5.x + e5.y) * h, (e5.y - e5.x) * h);
+    const float2 b6 = make_float2(e6.y, -e6.x);
+    const float2 b7 = make_float2((e7.y - e7.x) * h, -(e7.x + e7.y) * h);
+    pm_dft4(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
+    pm_dft4(b4, b5, b6, b7, a[1], a[3], a[5], a[7]);
+}
+
+// Orders the lanes' LDS accesses of one wave: the exchanges below hand data
+// from lane to lane through LDS without a workgroup barrier (a wave's DS
+// instructions execute in order), so the compiler must not move this thread's
+// reads above the other lanes' writes.
+__device__ __forceinline__ void pm_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+// EPI 4 keeps the mel filters' non-zero spans (2 x 513 + rounding values for
+// librosa's 80 triangles) in LDS when they fit
+#define PM_FFT_MEL_CAP 2048
+template <int EPI, int NW, int FPW>
+__host__ __device__ constexpr int pm_fft_smem_bytes() {
+    constexpr int FR = NW * FPW;
+    return NW * 576 * 8 + (EPI == 2 ? 0 : PM_FFT_BINS * (FR + 1) * 4) +
+           (EPI == 4 ? PM_FFT_MEL_CAP * 4 : 0);
+}
+
+// The 1024 samples of frame t as 8 x (x[2 (64 i + lane)], x[.. + 1]): padded
+// position p = 256 t + n maps to audio sample p - 384, reflected at both ends
+// (torch.nn.functional.pad(mode='reflect'), spectrogram.py:36-37).
+__device__ __forceinline__ void pm_fft_load_frame(
+    float2 (&raw)[8], const float* __restrict__ ab, int t, int N, int lane) {
+    const int base = t * PM_FFT_HOP - PM_FFT_PAD;
+    if (base >= 0 && base + PM_FFT_N <= N) {          // (wave-uniform)
+        const float* p = ab + base + 2 * lane;
+        if ((reinterpret_cast<uintptr_t>(p) & 7) == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                raw[i] = *reinterpret_cast<const float2*>(p + 128 * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                raw[i] = make_float2(p[128 * i], p[128 * i + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int j = base + 2 * (64 * i + lane) + e;
+                j = j < 0 ? -j : j;
+                j = j >= N ? 2 * (N - 1) - j : j;
+                v[e] = ab[j];
+            }
+            raw[i] = make_float2(v[0], v[1]);
+        }
+    }
+}
+
+template <int EPI, int NW, int FPW>
+__global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
+    constexpr int FR = NW * FPW;
+    constexpr int NT = NW * 64;
+    constexpr int WS = 576;          // complex slots per wave (8 x 72)
+    constexpr int OS = FR + 1;       // staging row pitch (floats)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* work = reinterpret_cast<float2*>(smem);
+    [[maybe_unused]] float* ost = reinterpret_cast<float*>(work + NW * WS);
+    [[maybe_unused]] float* melv = ost + PM_FFT_BINS * OS;   // EPI 4
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * FR;
+    const int T = a.T, N = a.N;
+    const float* __restrict__ ab = a.audio + (size_t)b * N;
+
+    // the first frame's samples are requested before anything else
+    float2 raw[8];
+    if (t0 + wave < T) pm_fft_load_frame(raw, ab, t0 + wave, N, lane);
+
+    [[maybe_unused]] bool mel_in_lds = false;
+    if constexpr (EPI == 4) {
+        const int nnz = a.mel_span[3 * a.rows];
+        mel_in_lds = nnz <= PM_FFT_MEL_CAP;
+        if (mel_in_lds)
+            for (int i = tid; i < nnz; i += NT) melv[i] = a.mel_vals[i];
+    }
+
+    // ---- per-lane constants -------------------------------------------------
+    const float* __restrict__ tab = a.tables;
+    const float2* __restrict__ w512 =
+        reinterpret_cast<const float2*>(tab + PM_FFT_TAB_W512);
+    const float2* __restrict__ w1024 =
+        reinterpret_cast<const float2*>(tab + PM_FFT_TAB_W1024);
+    const int k0p = lane >> 3, m0p = lane & 7;
+    float2 win[8], twa[8], twb[8], twp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        win[i] = *reinterpret_cast<const float2*>(tab + 2 * (64 * i + lane));
+        twa[i] = w512[lane * i];            // W512^(m k0), m = lane
+        twb[i] = w512[8 * m0p * i];         // W64^(m0 q0)
+        twp[i] = w1024[lane + 64 * i];      // W1024^k, k = lane + 64 j
+    }
+    float local_max = -INFINITY;
+    [[maybe_unused]] float floor_db = 0.f;
+    if constexpr (EPI == 3)
+        floor_db = pm_float_from_order_bits(a.maxbits[b]) - a.top_db;
+
+    float2* wk = work + wave * WS;
+#pragma unroll 1
+    for (int i = 0; i < FPW; ++i) {
+        const int fl = wave + NW * i;       // frame of this workgroup
+        if (t0 + fl >= T) break;            // (wave-uniform)
+        float2 z[8];
+        // stage A: lane m holds z[64 n2 + m], n2 = 0..7
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2)
+            z[n2] = make_float2(raw[n2].x * win[n2].x, raw[n2].y * win[n2].y);
+        // (the next frame's samples fly under this frame's transform)
+        if (i + 1 < FPW && t0 + fl + NW < T)
+            pm_fft_load_frame(raw, ab, t0 + fl + NW, N, lane);
+        pm_radix8(z);
+#pragma unroll
+        for (int k0 = 1; k0 < 8; ++k0) z[k0] = pm_cmul(z[k0], twa[k0]);
+        pm_wave_lds_sync();                 // (previous frame's reads of wk)
+#pragma unroll
+        for (int k0 = 0; k0 < 8; ++k0) wk[k0 * 72 + lane] = z[k0];
+        pm_wave_lds_sync();
+        // stage B: lane (k0, m0) takes m1 = 0..7 of sequence k0
+#pragma unroll
+        for (int m1 = 0; m1 < 8; ++m1) z[m1] = wk[k0p * 72 + 8 * m1 + m0p];
+        pm_radix8(z);
+#pragma unroll
+        for (int q0 = 1; q0 < 8; ++q0) z[q0] = pm_cmul(z[q0], twb[q0]);
+        pm_wave_lds_sync();
+#pragma unroll
+        for (int q0 = 0; q0 < 8; ++q0) wk[k0p * 72 + q0 * 9 + m0p] = z[q0];
+        pm_wave_lds_sync();
+        // stage C: lane (k0, q0) takes m0 = 0..7
+#pragma unroll
+        for (int m0 = 0; m0 < 8; ++m0) z[m0] = wk[k0p * 72 + m0p * 9 + m0];
+        pm_radix8(z);
+        // z[q1] = Z[k0 + 8 q0 + 64 q1]: natural order for the unpacking
+        pm_wave_lds_sync();
+#pragma unroll
+        for (int q1 = 0; q1 < 8; ++q1) wk[k0p + 8 * m0p + 64 * q1] = z[q1];
+        pm_wave_lds_sync();
+        // unpack: X[k] = (Z[k] + conj Z[512 - k]) / 2
+        //                + W1024^k (Z[k] - conj Z[512 - k]) / (2 i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            const float2 zk = wk[k];
+            const float2 zm = wk[(512 - k) & 511];
+            const float ex = 0.5f * (zk.x + zm.x), ey = 0.5f * (zk.y - zm.y);
+            const float dx = 0.5f * (zk.x - zm.x), dy = 0.5f * (zk.y + zm.y);
+            const float2 xo = make_float2(dy, -dx);
+            const float2 wx = pm_cmul(xo, twp[j]);
+            const float re = ex + wx.x, im = ey + wx.y;
+            const float pw = re * re + im * im;
+            if constexpr (EPI == 1 || EPI == 4) {
+                ost[k * OS + fl] = sqrtf(pw + 1e-6f);
+            } else {
+                const float v = 10.f * log10f(fmaxf(1e-10f, pw));
+                if constexpr (EPI == 2) {
+                    local_max = fmaxf(local_max, v);
+                } else {
+                    float u = fmaxf(v, floor_db) + a.weights[k];
+                    u = u < a.min_db ? a.min_db : u;
+                    ost[k * OS + fl] = u;
+                }
+            }
+        }
+        if (lane == 0) {                    // bin 512: Re Z[0] - Im Z[0]
+            const float2 z0 = wk[0];
+            const float re = z0.x - z0.y;
+            const float pw = re * re;
+            if constexpr (EPI == 1 || EPI == 4) {
+                ost[512 * OS + fl] = sqrtf(pw + 1e-6f);
+            } else {
+                const float v = 10.f * log10f(fmaxf(1e-10f, pw));
+                if constexpr (EPI == 2) {
+                    local_max = fmaxf(local_max, v);
+                } else {
+                    float u = fmaxf(v, floor_db) + a.weights[512];
+                    u = u < a.min_db ? a.min_db : u;
+                    ost[512 * OS + fl] = u;
+                }
+            }
+        }
+    }
+
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            local_max = fmaxf(local_max, __shfl_xor(local_max, o, 64));
+        if (lane == 0 && local_max > -INFINITY)
+            atomicMax(a.maxbits + b, pm_float_order_bits(local_max));
+        return;
+    }
+    __syncthreads();
+    const int nf = min(FR, T - t0);         // frames this workgroup owns
+    if (EPI == 1 || (EPI == 3 && a.rows == PM_FFT_BINS)) {
+        float* ob = a.out + (size_t)b * PM_FFT_BINS * T + t0;
+        for (int idx = tid; idx < PM_FFT_BINS * FR; idx += NT) {
+            const int bin = idx / FR, c = idx % FR;
+            if (c < nf) ob[(size_t)bin * T + c] = ost[bin * OS + c];
+        }
+    } else if constexpr (EPI == 3) {
+        // band means, rows summed in ascending order (loudness.py:96-111)
+        float* ob = a.out + (size_t)b * a.rows * T + t0;
+        for (int idx = tid; idx < a.rows * FR; idx += NT) {
+            const int band = idx / FR, c = idx % FR;
+            if (c >= nf) continue;
+            const int r0 = a.band_start[band], r1 = a.band_start[band + 1];
+            float s = 0.f;
+            for (int f = r0; f < r1; ++f) s += ost[f * OS + c];
+            ob[(size_t)band * T + c] = s / (float)(r1 - r0);
+        }
+    } else if constexpr (EPI == 4) {
+        // log(basis @ magnitude) over each filter's non-zero span, ascending
+        float* ob = a.out + (size_t)b * a.rows * T + t0;
+        for (int idx = tid; idx < a.rows * FR; idx += NT) {
+            const int m = idx / FR, c = idx % FR;
+            if (c >= nf) continue;
+            const int lo = a.mel_span[3 * m], hi = a.mel_span[3 * m + 1];
+            const float* bv = (mel_in_lds ? melv : a.mel_vals) +
+                              a.mel_span[3 * m + 2];
+            const float* sp = ost + lo * OS + c;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int f = 0; f < hi - lo; ++f)
+                acc = fmaf(bv[f], sp[f * OS], acc);
+            float v = logf(acc);
+            if (a.use_thr) v = fmaxf(v, a.thr);
+            ob[(size_t)m * T + c] = v;
+        }
+    }
+}
+
+// Compact form of a (M, F) filterbank: per row the first / one-past-last
+// non-zero column and the offset of that span in `vals`, then the total count.
+// One workgroup; M <= 1024.
+__global__ __launch_bounds__(256) void pm_mel_csr_kernel(
+    const float* __restrict__ basis, int* __restrict__ table,
+    float* __restrict__ vals, int M, int F) {
+    __shared__ int lo_s[1024], hi_s[1024], off_s[1025];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m = wave; m < M; m += 4) {
+        const float* br = basis + (size_t)m * F;
+        int lo = F, hi = 0;
+        for (int f = lane; f < F; f += 64)
+            if (br[f] != 0.f) { lo = min(lo, f); hi = max(hi, f + 1); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, 64));
+            hi = max(hi, __shfl_xor(hi, o, 64));
+        }
+        if (lane == 0) { lo_s[m] = hi > lo ? lo : 0; hi_s[m] = hi > lo ? hi : 0; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int m = 0; m < M; ++m) { off_s[m] = total; total += hi_s[m] - lo_s[m]; }
+        off_s[M] = total;
+        table[3 * M] = total;
+    }
+    __syncthreads();
+    for (int m = wave; m < M; m += 4) {
+        if (lane == 0) {
+            table[3 * m] = lo_s[m]; table[3 * m + 1] = hi_s[m];
+            table[3 * m + 2] = off_s[m];
+        }
+        for (int f = lo_s[m] + lane; f < hi_s[m]; f += 64)
+            vals[off_s[m] + f - lo_s[m]] = basis[(size_t)m * F + f];
+    }
+}

@@ -29,6 +29,32 @@ inline hipError_t pm_ensure_dynamic_lds(const void* kern, int bytes) {
     return hipSuccess;
 }
 
+// Compute units of the current device, queried once per device (the walked
+// launchers size their grids from it on every forward).
+inline int pm_device_cus() {
+    static std::mutex guard;
+    static std::map<int, int> cus_of;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lock(guard);
+    auto it = cus_of.find(dev);
+    if (it != cus_of.end()) return it->second;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
+                              dev) != hipSuccess)
+        cus = 0;
+    cus_of[dev] = cus;
+    return cus;
+}
+
+// Test hooks (pm_debug_force): the walked kernels and the multi-block path of
+// the wide upsampler are chosen from the grid size, which unit-sized inputs
+// never reach. walk_nseg > 0: take the walked variant wherever it exists, with
+// that many segments per utterance; upsample_groups > 0: that many M groups
+// per column tile. 0 = the production heuristics.
+struct PmForce { int walk_nseg = 0; int upsample_groups = 0; };
+inline PmForce& pm_force() { static PmForce f; return f; }
+
 // Latency (narrow-tile) variants can be switched off for A/B runs in a
 // -DPM_TUNING build only; the shipped library reads no environment.
 inline bool pm_narrow_allowed() {
@@ -253,14 +279,12 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
     if constexpr (ET::ESZ == 2 && WM * WN == 8) {
         const int smem_walk = block3_walk_smem_bytes<ET, C, K, WM, WN, NTW>() +
                               block3_carry_bytes<ET, C>(a.halo);
-        int dev = 0, cus = 0;
-        if (a.niter <= 3 && smem_walk <= 160 * 1024 &&
-            hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
-                                  dev) == hipSuccess && cus > 0) {
-            int nseg = cus / a.B;
+        const int cus = pm_device_cus();
+        const int forced = pm_force().walk_nseg;
+        if (a.niter <= 3 && smem_walk <= 160 * 1024 && (cus > 0 || forced)) {
+            int nseg = forced ? forced : cus / a.B;
             if (nseg < 1) nseg = 1;
-            if ((a.L / (NC - a.halo)) / nseg >= 6) {
+            if (forced || (a.L / (NC - a.halo)) / nseg >= 6) {
                 Block3WalkArgs p;
                 p.a = a; p.nseg = nseg;
                 auto walk = conv_block3_walk_kernel<ET, C, K, WM, WN, NTW>;
@@ -349,17 +373,16 @@ static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stre
     // segment) with enough tiles per segment to amortise its two-sided first
     // tile; the sum-in-registers geometry (C = 32) only.
     if constexpr (C == 32 && ET::ESZ == 2 && WM * WN == 8) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
-                                  dev) == hipSuccess && cus > 0 &&
+        const int cus = pm_device_cus();
+        const int forced = pm_force().walk_nseg;
+        if ((cus > 0 || forced) &&
             m.k[0].niter == 3 && m.k[1].niter == 3 && m.k[2].niter == 3) {
             const int B = m.k[0].B, L = m.k[0].L;
             const int step = NC - halo;
-            int nseg = cus / B;
+            int nseg = forced ? forced : cus / B;
             if (nseg < 1) nseg = 1;
             const int tiles_per_seg = (L / step) / nseg;
-            if (tiles_per_seg >= 8) {
+            if (forced || tiles_per_seg >= 8) {
                 MrfWalkArgs wa = {};
                 wa.x = m.k[0].x; wa.out = m.k[0].out;
                 for (int j = 0; j < 3; ++j)
@@ -523,6 +546,8 @@ static hipError_t launch_upsample_cfg(const SingleArgs& a0, hipStream_t stream) 
     int groups = 1;
     while (groups < mblocks && (long long)a.ntiles * a.B * groups < 512)
         groups *= 2;
+    if (pm_force().upsample_groups > 0) groups = pm_force().upsample_groups;
+    if (groups > mblocks) groups = mblocks;
     while (mblocks % groups) groups /= 2;
     a.nmblocks = groups;
     auto kern = conv_upsample_kernel<ET, CIN, WM, WN, MTW, NTW>;
@@ -550,7 +575,8 @@ hipError_t pm_launch_single(
 }
 
 // Framed DFT (STFT) as a 4-tap conv over the hop-reshaped padded audio:
-// exact-fp32 MFMA only. epi 1: magnitude, 2: dB + utterance max, 3: the DFT
+// exact-fp32 MFMA only (the forward transforms run as FFTs, pm_fft.h; this is
+// the backward and the brute-force cross-check). epi 1: magnitude, 3: the DFT
 // cotangent grad / magnitude * (re, im) (backward, first half), 0: the
 // overlap-add conv of that cotangent against the transposed basis (backward,
 // second half: C_in = 1088 -> 256 samples of one hop, 4 taps).
@@ -558,8 +584,6 @@ hipError_t pm_launch_single(
 hipError_t pm_launch_stft(int epi, const SingleArgs& a, hipStream_t s) {
     if (epi == 1)
         return launch_single_cfg<ElemF32, 4, 4, 64, 2, 2, 1, 2, 1>(a, s);
-    if (epi == 2)
-        return launch_single_cfg<ElemF32, 4, 4, 64, 2, 2, 1, 2, 2>(a, s);
     if (epi == 3)
         return launch_single_cfg<ElemF32, 4, 4, 64, 2, 2, 1, 2, 3>(a, s);
     if (epi == 0)

@@ -1,11 +1,13 @@
-// Framed STFT / mel / A-weighted loudness preprocessing kernels.
+// Framed-DFT formulation of the STFT (the BACKWARD pass of
+// spectrogram.from_audio, and a brute-force cross-check of the forward FFT of
+// pm_fft.h) and the stand-alone mel kernels.
 // Reference: promonet/preprocess/spectrogram.py, promonet/preprocess/loudness.py
 //
 // The 1024-point hann-windowed DFT at hop 256 is a 4-tap convolution over the
 // padded audio viewed as (frames + 3, 256) "channels-last" rows, so it runs on
-// the exact-fp32 MFMA conv kernel (pm_conv.h, EPI 1/2) against a precomputed
-// (re, im)-interleaved windowed DFT basis; magnitude / dB conversion happen in
-// the MFMA epilogue and the spectrogram is written once, (B, 513, T).
+// the exact-fp32 MFMA conv kernel (pm_conv.h, EPI 1/3) against a precomputed
+// (re, im)-interleaved windowed DFT basis. The adjoint of a linear map is the
+// same GEMM transposed, which is why the backward keeps this form.
 #pragma once
 #include "pm_common.h"
 
@@ -155,36 +157,4 @@ __global__ __launch_bounds__(256) void pm_mel_kernel(
 
 __device__ __forceinline__ float pm_float_from_order_bits(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-
-// loudness.from_audio tail (loudness.py:46-55) + band_average (:84-111):
-// db (B, F, T) -> max(db, gmax - 80) + a_weight[f], floored at min_db, then
-// mean over band rows [start[b], start[b+1]).
-struct LoudnessArgs {
-    const float* db;
-    const unsigned* maxbits;
-    const float* weights;
-    float* out;
-    int F, T, bands;
-    int band_start[17];
-    float min_db, top_db;
-};
-
-__global__ __launch_bounds__(256) void pm_loudness_bands_kernel(
-    LoudnessArgs a) {
-    const int b = blockIdx.z, band = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= a.T) return;
-    const float floor_db = pm_float_from_order_bits(a.maxbits[b]) - a.top_db;
-    const float* dp = a.db + (size_t)b * a.F * a.T + t;
-    // bands == F: no averaging (`bands=None` in the reference API)
-    const int r0 = a.bands == a.F ? band : a.band_start[band];
-    const int r1 = a.bands == a.F ? band + 1 : a.band_start[band + 1];
-    float s = 0.f;
-    for (int f = r0; f < r1; ++f) {
-        float v = fmaxf(dp[(size_t)f * a.T], floor_db) + a.weights[f];
-        v = v < a.min_db ? a.min_db : v;
-        s += v;
-    }
-    a.out[((size_t)b * a.bands + band) * a.T + t] = s / (float)(r1 - r0);
 }

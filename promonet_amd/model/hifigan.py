@@ -135,7 +135,17 @@ class HiFiGAN(torch.nn.Module):
                 raise ValueError('ragged dilation lists are not supported')
             for n, d in enumerate(self.res_dilations[j]):
                 config.resblock_dilations[j][n] = d
-        config.compute_dtype = _lib.DTYPES[self.compute_dtype]
+        # 'bf16' / 'f16' / 'fp32', or one operand type per upsampling stage
+        # joined by '+' ('bf16+bf16+f16+f16': the input conv takes the first)
+        per_stage = str(self.compute_dtype).split('+')
+        if len(per_stage) not in (1, len(self.rates)):
+            raise ValueError(
+                f'COMPUTE_DTYPE {self.compute_dtype!r}: one operand type, or '
+                f'one per stage ({len(self.rates)})')
+        config.compute_dtype = _lib.DTYPES[per_stage[0]]
+        if len(per_stage) > 1:
+            for i, name in enumerate(per_stage):
+                config.stage_compute_dtype[i] = 1 + _lib.DTYPES[name]
         handle = ctypes.c_void_p()
         with torch.cuda.device(first.device):
             _lib.check(lib.pm_hifigan_create(

@@ -32,11 +32,49 @@ def from_audio(
         # training-side use (the mel loss, train/core.py:277-305): keep the
         # graph through the HIP kernels
         out = _Magnitude.apply(flat)
+    elif mels:
+        # inference: log-mel straight out of the FFT kernel, the (B, 513, T)
+        # magnitudes never reach HBM
+        return _log_mel(
+            flat, log_dynamic_range_compression_threshold).squeeze(0)
     else:
         out = _magnitude(flat)
     if mels:
         out = linear_to_mel(out, log_dynamic_range_compression_threshold)
     return out.squeeze(0)
+
+
+def _log_mel(flat, threshold):
+    lib = _lib.lib()
+    batch, samples = flat.shape
+    frames = samples // promonet_amd.HOPSIZE
+    mels = promonet_amd.NUM_MELS
+    out = torch.empty(batch, mels, frames, device=flat.device)
+    with torch.cuda.device(flat.device):
+        _lib.check(lib.pm_stft_mel(
+            _lib.ptr(flat), _prepared_mel_basis(flat.device).data_ptr(),
+            _lib.ptr(out), batch, samples, mels, int(threshold is not None),
+            float(threshold or 0.), _lib.stream()))
+    return out
+
+
+def _prepared_mel_basis(device):
+    """The mel filterbank in the compact form the fused kernel reads, built
+    once per device (and per configuration)."""
+    key = (device, promonet_amd.SAMPLE_RATE, promonet_amd.NUM_FFT,
+           promonet_amd.NUM_MELS)
+    cache = _prepared_mel_basis.__dict__.setdefault('cache', {})
+    if key not in cache:
+        lib = _lib.lib()
+        basis = mel_basis().to(device).contiguous()
+        with torch.cuda.device(device):
+            size = lib.pm_stft_mel_scratch_bytes(basis.shape[0])
+            prepared = torch.empty(size, dtype=torch.uint8, device=device)
+            _lib.check(lib.pm_stft_mel_prepare(
+                _lib.ptr(basis), basis.shape[0], prepared.data_ptr(),
+                prepared.numel(), _lib.stream()))
+        cache[key] = prepared
+    return cache[key]
 
 
 def _magnitude(flat):
@@ -46,12 +84,10 @@ def _magnitude(flat):
     bins = promonet_amd.NUM_FFT // 2 + 1
     out = torch.empty(batch, bins, frames, device=flat.device)
     with torch.cuda.device(flat.device):
-        size = lib.pm_stft_scratch_bytes(batch, samples)
-        scratch = torch.empty(
-            max(size, 1), dtype=torch.uint8, device=flat.device)
+        # (a real FFT per frame in LDS: no scratch)
         _lib.check(lib.pm_stft_magnitude(
-            _lib.ptr(flat), _lib.ptr(out), batch, samples,
-            scratch.data_ptr(), scratch.numel(), _lib.stream()))
+            _lib.ptr(flat), _lib.ptr(out), batch, samples, None, 0,
+            _lib.stream()))
     return out
 
 

@@ -49,6 +49,42 @@ with torch.inference_mode():
             'ms': seconds_per * 1e3,
             'audio_seconds_per_second': batch * seconds / seconds_per,
             'dft_tflops': dft_flops / seconds_per / 1e12}
+    # kernels alone: the C ABI on preallocated buffers (no allocation, no
+    # Python wrapper), both FFT workgroup shapes
+    from promonet_amd import _lib
+    lib = _lib.lib()
+    flat = audio_gpu[:, 0].contiguous()
+    spec = torch.empty(batch, bins, frames, device=device)
+    mel = torch.empty(batch, 80, frames, device=device)
+    loud = torch.empty(batch, 8, frames, device=device)
+    basis = promonet_amd.preprocess.spectrogram.mel_basis().to(device).contiguous()
+    weights = promonet_amd.preprocess.loudness.perceptual_weights_tensor(device)
+    scratch = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+    stream = _lib.stream()
+    prepared = promonet_amd.preprocess.spectrogram._prepared_mel_basis(device)
+    abi = {
+        'spectrogram': lambda: lib.pm_stft_magnitude(
+            _lib.ptr(flat), _lib.ptr(spec), batch, samples, None, 0, stream),
+        'log_mel': lambda: lib.pm_stft_mel(
+            _lib.ptr(flat), prepared.data_ptr(), _lib.ptr(mel), batch, samples,
+            80, 0, 0., stream),
+        'loudness_8_bands': lambda: lib.pm_loudness(
+            _lib.ptr(flat), _lib.ptr(weights), _lib.ptr(loud), batch, samples,
+            8, -100., scratch.data_ptr(), scratch.numel(), stream),
+    }
+    in_bytes, frame_bytes = 4. * batch * samples, 4. * batch * frames
+    algorithmic = {'spectrogram': in_bytes + bins * frame_bytes,
+                   'log_mel': in_bytes + 80 * frame_bytes,
+                   'loudness_8_bands': 2 * in_bytes + 8 * frame_bytes}
+    for group in (16, 32):
+        _lib.check(lib.pm_stft_set_frames_per_group(group))
+        for name, fn in abi.items():
+            seconds_per = timed(fn, reps=200)
+            result[f'{name}_abi_group{group}'] = {
+                'ms': seconds_per * 1e3,
+                'algorithmic_gbs': algorithmic[name] / seconds_per / 1e9,
+                'frac_of_8tbs': algorithmic[name] / seconds_per / 8e12}
+    _lib.check(lib.pm_stft_set_frames_per_group(16))
     # CPU port on 2 utterances
     cpu_audio = audio[:2]
     cpu = {}

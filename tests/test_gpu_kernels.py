@@ -142,7 +142,21 @@ def test_whole_block(device, dtype, channels, kernel_size):
         return (ctypes.c_void_p * 3)(*[t.data_ptr() for t in on_device[name]])
 
     if channels == 128 and (kernel_size != 3 or dtype == 'fp32'):
-        pytest.skip('no whole-Block instantiation (halo too wide): pair path')
+        # (C = 128 k 7 exists as a WALKED whole Block only: covered by
+        # test_walked_whole_block; k 11 and fp32 run on the pair kernel)
+        with pytest.raises(RuntimeError, match='no whole-Block kernel'):
+            x_cl = torch.zeros(1, 64, channels, device=device)
+            _lib.check(_lib.lib().pm_block_cl(
+                _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(x_cl),
+                pointers('w1'), pointers('b1'), pointers('w2'), pointers('b2'),
+                (ctypes.c_int * 3)(*dilations), 3, 1, 64, channels, kernel_size,
+                0, 1., torch.empty(
+                    3 * _lib.lib().pm_op_workspace_bytes(
+                        channels, channels, kernel_size),
+                    dtype=torch.uint8, device=device).data_ptr(),
+                3 * _lib.lib().pm_op_workspace_bytes(
+                    channels, channels, kernel_size), _lib.stream()))
+        return
     dil = (ctypes.c_int * 3)(*dilations)
     ws = torch.empty(
         3 * _lib.lib().pm_op_workspace_bytes(channels, channels, kernel_size),
@@ -167,18 +181,103 @@ def test_whole_block(device, dtype, channels, kernel_size):
         assert rel_err(from_cl(out, channels), want) < tolerance, (length, mode)
 
 
+def block_fixture(channels, kernel_size, gen, device, prefix='p'):
+    std = 1. / (channels * kernel_size) ** .5
+    state, tensors = {}, {'w1': [], 'b1': [], 'w2': [], 'b2': []}
+    for n in range(3):
+        for which in (1, 2):
+            w = torch.randn(channels, channels, kernel_size, generator=gen) * std
+            b = torch.randn(channels, generator=gen) * .1
+            state[f'{prefix}.convs{which}.{n}.weight'] = w
+            state[f'{prefix}.convs{which}.{n}.bias'] = b
+            tensors[f'w{which}'].append(w.to(device).contiguous())
+            tensors[f'b{which}'].append(b.to(device).contiguous())
+    return state, tensors
+
+
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+@pytest.mark.parametrize(
+    'channels,kernel_size',
+    [(64, 3), (64, 7), (64, 11), (128, 3), (128, 7), (256, 3)])
+def test_walked_whole_block(device, dtype, channels, kernel_size):
+    """The WALKED whole-Block kernels (conv_block3_walk_kernel: a workgroup
+    walks its tiles left to right, every layer's last columns carried through
+    LDS) at kernel level against the oracle - the production launcher only
+    takes them for grids that fill the chip several times (16 % of the
+    batch-32 x 10 s step runs in C = 128 k 7 and C = 256 k 3, which exist in
+    no other form). Forced through pm_debug_force with 2 and 3 segments per
+    utterance: >= 8 tiles per segment, uneven segments, an utterance end
+    inside a tile, a segment boundary that is no tile multiple, mode 2."""
+    _lib = lib()
+    gen = torch.Generator().manual_seed(1000 + channels + kernel_size)
+    dilations = (1, 3, 5)
+    state, tensors = block_fixture(channels, kernel_size, gen, device)
+
+    def pointers(name):
+        return (ctypes.c_void_p * 3)(*[t.data_ptr() for t in tensors[name]])
+
+    dil = (ctypes.c_int * 3)(*dilations)
+    size = 3 * _lib.lib().pm_op_workspace_bytes(channels, channels, kernel_size)
+    ws = torch.empty(size, dtype=torch.uint8, device=device)
+    # columns a walked tile advances by: NC - halo
+    columns = {64: 256 if kernel_size == 3 else 512, 128: 256, 256: 128}[channels]
+    halo = sum((d + 1) * (kernel_size // 2) for d in dilations)
+    step = columns - halo
+    try:
+        for nseg, length, mode in (
+                (2, 16 * step + 37, 0), (3, 25 * step - 5, 2), (2, 61, 1)):
+            _lib.check(_lib.lib().pm_debug_force(nseg, 0))
+            x = torch.randn(2, channels, length, generator=gen)
+            prev = torch.randn(2, channels, length, generator=gen)
+            want = oracle.block(x, state, 'p', kernel_size, dilations)
+            want = {0: want, 1: want / 3, 2: prev + want / 3}[mode]
+            x_cl = to_cl(x).to(device)
+            out = to_cl(prev).to(device)
+            _lib.check(_lib.lib().pm_block_cl(
+                _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out),
+                pointers('w1'), pointers('b1'), pointers('w2'), pointers('b2'),
+                dil, 3, 2, length, channels, kernel_size, mode, 1 / 3,
+                ws.data_ptr(), ws.numel(), _lib.stream()))
+            torch.cuda.synchronize()
+            error = rel_err(from_cl(out, channels), want)
+            print(f'walked block C {channels} k {kernel_size} {dtype} nseg '
+                  f'{nseg} L {length}: rel {error:.3e}')
+            assert error < 3 * TOL[dtype], (nseg, length, mode)
+            if channels <= 128 and (channels, kernel_size) != (128, 7):
+                # bit-identical to the stand-alone (two-sided halo) tiling
+                _lib.check(_lib.lib().pm_debug_force(0, 0))
+                plain = to_cl(prev).to(device)
+                _lib.check(_lib.lib().pm_block_cl(
+                    _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(plain),
+                    pointers('w1'), pointers('b1'), pointers('w2'),
+                    pointers('b2'), dil, 3, 2, length, channels, kernel_size,
+                    mode, 1 / 3, ws.data_ptr(), ws.numel(), _lib.stream()))
+                torch.cuda.synchronize()
+                assert torch.equal(plain, out), (nseg, length)
+    finally:
+        _lib.check(_lib.lib().pm_debug_force(0, 0))
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
 @pytest.mark.parametrize(
     'c_in,c_out,rate',
     [(512, 256, 8), (256, 128, 8), (128, 64, 2), (64, 32, 2), (64, 32, 8),
      (32, 16, 2), (16, 8, 4)])
 def test_conv_transpose(device, dtype, c_in, c_out, rate):
-    # (the two wide r = 8 shapes run conv_upsample_kernel with 16-bit operands:
-    # 130 / 300 columns = 2 / 3 column tiles, M groups of several 256-row blocks)
+    # (the two wide r = 8 shapes run conv_upsample_kernel with 16-bit operands.
+    # With inputs this small its launcher gives every 256-row M block its own
+    # workgroup; the production path - ONE workgroup streaming the weights of
+    # all 4 / 8 M blocks past a staged x tile, the next block's first
+    # fragments prefetched - is reached through pm_debug_force(0, groups))
     _lib = lib()
     gen = torch.Generator().manual_seed(c_in + rate)
     k = 2 * rate
-    for length in (1, 5, 130, 300):
+    wide = rate == 8 and c_in >= 256 and dtype != 'fp32'
+    cases = [(length, 0) for length in (1, 5, 130, 300)]
+    if wide:
+        cases += [(300, 1), (131, 2)]
+    for length, groups in cases:
+        _lib.check(_lib.lib().pm_debug_force(0, groups))
         x = torch.randn(2, c_in, length, generator=gen)
         w = torch.randn(c_in, c_out, k, generator=gen) / (c_in * 2) ** .5
         bias = torch.randn(c_out, generator=gen) * .1
@@ -195,7 +294,8 @@ def test_conv_transpose(device, dtype, c_in, c_out, rate):
             _lib.ptr(bd), 2, length, c_in, c_out, rate, 1, ws.data_ptr(),
             ws.numel(), _lib.stream()))
         torch.cuda.synchronize()
-        assert rel_err(from_cl(out, c_out), want) < TOL[dtype], length
+        _lib.check(_lib.lib().pm_debug_force(0, 0))
+        assert rel_err(from_cl(out, c_out), want) < TOL[dtype], (length, groups)
 
 
 def test_out_conv_tanh(device):
@@ -270,6 +370,31 @@ def test_whole_mrf(device, dtype, channels):
         torch.cuda.synchronize()
         got = from_cl(out, channels).cpu()
         assert rel_err(got, want) < 2 * TOL[dtype], (length, dtype)
+    if dtype != 'fp32':
+        # the walked whole-MRF kernel (conv_mrf_walk_kernel), which the
+        # launcher only takes from 8 tiles per segment on: forced, 2 and 3
+        # segments, ragged segment ends; bit-identical to the stand-alone tiling
+        try:
+            for nseg, length in ((2, 12000), (3, 9973), (2, 700)):
+                x = torch.randn(2, channels, length, generator=gen)
+                want = oracle.residual_block(x, state, 'p')
+                x_cl = to_cl(x).to(device)
+                outs = []
+                for force in (nseg, 0):
+                    _lib.check(_lib.lib().pm_debug_force(force, 0))
+                    out = torch.full_like(x_cl, 7.)
+                    _lib.check(_lib.lib().pm_mrf_cl(
+                        _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out),
+                        pointers('w1'), pointers('b1'), pointers('w2'),
+                        pointers('b2'), dil, 3, 2, length, channels,
+                        ws.data_ptr(), ws.numel(), _lib.stream()))
+                    torch.cuda.synchronize()
+                    outs.append(out)
+                got = from_cl(outs[0], channels).cpu()
+                assert rel_err(got, want) < 2 * TOL[dtype], (nseg, length)
+                assert torch.equal(outs[0], outs[1]), (nseg, length)
+        finally:
+            _lib.check(_lib.lib().pm_debug_force(0, 0))
     with pytest.raises(RuntimeError):
         x_cl = torch.zeros(1, 8, 64, device=device)
         _lib.check(_lib.lib().pm_mrf_cl(
