@@ -225,37 +225,23 @@ def main():
     inputs = synthetic_inputs(args.batch, frames, 1234 + rank, device)
     gather = world > 1 and not args.no_gather
     backend = dist.get_backend() if world > 1 else None
-    overlap = gather and backend == 'nccl'
-    if gather:
-        # The all-gather of step k runs on RCCL's stream while step k + 1
-        # computes: two destination buffers, one is reused only after its
-        # collective has completed (the source is the forward's fresh output
-        # tensor, kept alive next to the work handle). Every collective is
-        # waited for inside the timed region.
-        gathered = [torch.empty(
-            world * args.batch, 1, frames * promonet_amd.HOPSIZE,
-            device=device) for _ in range(2)]
-    pending = [None, None]
-    counter = [0]
+    # N > 1: the all-gather of step k runs on RCCL's stream while step k + 1
+    # computes (promonet_amd.distributed.GatherPipeline: two destination
+    # buffers, every collective waited for inside the timed region)
+    pipeline = promonet_amd.distributed.GatherPipeline(
+        world, (args.batch, 1, frames * promonet_amd.HOPSIZE), device) \
+        if gather else None
+    overlap = gather and pipeline.overlap
 
     def step():
         audio = model(*inputs, None)
         if gather:
-            slot = counter[0] & 1
-            counter[0] += 1
-            if pending[slot] is not None and pending[slot][0] is not None:
-                pending[slot][0].wait()
-            work, _ = promonet_amd.distributed.all_gather_into(
-                audio, world, out=gathered[slot], async_op=True)
-            pending[slot] = (work, audio)
+            pipeline.submit(audio)
         return audio
 
     def drain():
-        for slot in range(2):
-            if pending[slot] is not None:
-                if pending[slot][0] is not None:
-                    pending[slot][0].wait()
-                pending[slot] = None
+        if gather:
+            pipeline.drain()
 
     def fence():
         drain()

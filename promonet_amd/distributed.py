@@ -15,9 +15,11 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
+def init(backend=None, force=False):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE /
     LOCAL_RANK / MASTER_ADDR / MASTER_PORT). Returns (rank, world, device).
+    `force` creates the process group for a single rank too (a 1-GPU box can
+    then drive RCCL's collectives, asynchronous overlap included).
 
     One rank per GPU over RCCL ("nccl"). When there are more local ranks than
     GPUs (a 1-GPU test box running the 2-rank path) the ranks fold onto the
@@ -33,7 +35,7 @@ def init(backend=None):
     device = torch.device(f'cuda:{index}' if use_gpu else 'cpu')
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         folded = use_gpu and local_world > devices
@@ -143,9 +145,55 @@ def all_gather_into(local, world=None, out=None, async_op=False):
     return (work, out) if async_op else out
 
 
+class GatherPipeline:
+    """The all-gather of step k's audio overlapped with the synthesis of step
+    k + 1: two destination buffers, a buffer is reused only after its
+    collective has completed. Over RCCL the collective is asynchronous (it
+    runs on RCCL's stream beside the caller's kernels; the source tensor is
+    kept alive next to the work handle); over gloo (ranks folded onto fewer
+    GPUs) it is synchronous and staged through host memory. `bench.py`'s step
+    for N > 1 and the config-4 test drive exactly this object."""
+
+    def __init__(self, world, shard_shape, device, dtype=torch.float32):
+        self.world = world
+        self.overlap = dist.is_initialized() and dist.get_backend() == 'nccl'
+        self.buffers = [
+            torch.empty(
+                (world * shard_shape[0],) + tuple(shard_shape[1:]),
+                dtype=dtype, device=device) for _ in range(2)]
+        self.pending = [None, None]
+        self.count = 0
+
+    def submit(self, audio):
+        """Start gathering `audio` (this rank's shard); returns the slot."""
+        slot = self.count & 1
+        self.count += 1
+        self.wait(slot)
+        work, _ = all_gather_into(
+            audio, self.world, out=self.buffers[slot], async_op=True)
+        self.pending[slot] = (work, audio)
+        return slot
+
+    def wait(self, slot):
+        if self.pending[slot] is not None:
+            if self.pending[slot][0] is not None:
+                self.pending[slot][0].wait()
+            self.pending[slot] = None
+
+    def result(self, slot):
+        """The gathered (world * B, ...) tensor of `slot`, complete."""
+        self.wait(slot)
+        return self.buffers[slot]
+
+    def drain(self):
+        for slot in range(2):
+            self.wait(slot)
+
+
 def synthesize_sharded(
     synthesize, loudness, pitch, periodicity, ppg, speakers,
-    spectral_balance_ratios, loudness_ratios, gather=True, hopsize=256
+    spectral_balance_ratios, loudness_ratios, gather=True, hopsize=None,
+    dtype=torch.float32
 ):
     """Run `synthesize` on this rank's shard of a (replicated) global batch.
 
@@ -153,8 +201,13 @@ def synthesize_sharded(
     (B_r, 1, S), e.g. `promonet_amd.model.Generator.forward`. Returns the
     gathered (B, 1, S) audio on every rank (or the local shard). With fewer
     utterances than ranks the surplus ranks synthesise nothing (the engine
-    rejects empty batches) and contribute an empty shard to the collective.
+    rejects empty batches) and contribute an empty shard to the collective:
+    `hopsize` (default: the configured promonet_amd.HOPSIZE) and `dtype` give
+    that shard the shape and type the other ranks' audio has.
     """
+    if hopsize is None:
+        import promonet_amd
+        hopsize = promonet_amd.HOPSIZE
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     total = pitch.shape[0]
@@ -166,6 +219,6 @@ def synthesize_sharded(
             spectral_balance_ratios[start:end], loudness_ratios[start:end])
     else:
         local = torch.zeros(
-            0, 1, pitch.shape[-1] * hopsize, dtype=torch.float32,
+            0, 1, pitch.shape[-1] * hopsize, dtype=dtype,
             device=pitch.device)
     return all_gather_audio(local, total, world) if gather else local

@@ -110,3 +110,101 @@ def test_bench_self_launches_two_ranks(device):
     result = json.loads(lines[0])
     assert result['n_gpus'] == 2 and result['world_size'] == 2
     assert result['value'] > 0 and result['scaling'] == 'weak'
+
+
+###############################################################################
+# BASELINE.json configs[3] at its real per-rank size
+###############################################################################
+
+
+def load_bench():
+    import importlib.util
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    spec = importlib.util.spec_from_file_location('bench', root / 'bench.py')
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    return module
+
+
+def config4_worker(rank, world, port, backend, results):
+    """One rank of the 8-GPU job at its real size: 32 utterances x 861 frames,
+    bf16, through the objects bench.py's N > 1 step is made of."""
+    os.environ.update(
+        RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+        LOCAL_WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+        MASTER_PORT=str(port))
+    bench = load_bench()
+    import torch.distributed as dist
+    import promonet_amd
+    from promonet_amd import distributed
+
+    _, _, device = distributed.init(backend=backend, force=True)
+    assert dist.get_backend() == backend
+    batch, frames = 32, 861
+    promonet_amd.configure(COMPUTE_DTYPE='bf16')
+    torch.manual_seed(rank)                  # broadcast makes them equal
+    model = promonet_amd.model.Generator().to(device).eval()
+    distributed.broadcast_model(model)
+    inputs = bench.synthetic_inputs(batch, frames, 1234 + rank, device)
+    pipeline = distributed.GatherPipeline(
+        world, (batch, 1, frames * promonet_amd.HOPSIZE), device)
+    assert pipeline.overlap == (backend == 'nccl')
+    with torch.inference_mode():
+        slots = []
+        for _ in range(3):                   # both buffers, one reused
+            slots.append(pipeline.submit(model(*inputs, None)))
+        pipeline.drain()
+        torch.cuda.synchronize()
+        assert slots == [0, 1, 0]
+        gathered = pipeline.result(0)            # the third step's
+        assert gathered.shape == (world * batch, 1, frames * 256)
+        assert torch.equal(pipeline.result(1), gathered)   # the second's
+        # three utterances of the gathered batch (every rank's shard is hit)
+        # against their stand-alone synthesis, bit for bit
+        gen = torch.Generator().manual_seed(5)
+        picks = [int(torch.randint(0, world * batch, (1,), generator=gen))
+                 for _ in range(2)] + [world * batch - 1]
+        for pick in picks:
+            owner, item = divmod(pick, batch)
+            theirs = bench.synthetic_inputs(batch, frames, 1234 + owner, device)
+            single = model(*[t[item:item + 1] for t in theirs], None)
+            assert torch.equal(single[0], gathered[pick]), pick
+    results.put((rank, float(gathered.abs().max()), gathered.shape[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_config4(world, backend):
+    context = mp.get_context('spawn')
+    results = context.Queue()
+    port = free_port()
+    processes = [
+        context.Process(
+            target=config4_worker, args=(rank, world, port, backend, results))
+        for rank in range(world)]
+    for process in processes:
+        process.start()
+    for process in processes:
+        process.join(900)
+        assert process.exitcode == 0
+    return sorted(results.get(timeout=5) for _ in range(world))
+
+
+def test_config4_rank_workload_two_ranks(device):
+    """Two ranks folded onto the one GPU, each with config 4's per-rank
+    workload (32 x 861 frames, 3.6 GB workspace, 2 x 226 MB gather buffers at
+    world 8 - here 2 x 56 MB), through bench.py's own step objects; collectives
+    over gloo (RCCL refuses two ranks on one device)."""
+    got = run_config4(2, 'gloo')
+    assert got[0][1] == got[1][1] > 0 and got[0][2] == 64
+
+
+def test_config4_rccl_overlap_one_rank(device):
+    """The asynchronous RCCL branch itself (all_gather_into_tensor on RCCL's
+    stream, overlapped with the next forward) with the real 28 MB shard: one
+    rank, backend nccl - what a single-GPU box can execute of it."""
+    got = run_config4(1, 'nccl')
+    assert got[0][1] > 0 and got[0][2] == 32
