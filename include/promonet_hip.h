@@ -265,12 +265,15 @@ int pm_grid_sample(const float* seq, const float* grid, float* out, int rows,
                    int n_in, int n_out, int mode, float scale, float offset,
                    float lo, float hi, void* stream);
 /* Selective time-stretch grid (edit/core.py:57-110, stretch_unvoiced /
- * stretch_silence off): ppg (P, frames), `indices` (n) = rows of the phonemes
- * that ARE stretched (device int32); writes selected (frames) = their summed
- * probability and grid (target_frames), the reference's sequential fp32
- * recurrence whose step follows that probability.                          */
-int pm_stretch_grid(const float* ppg, const int* indices, int n_indices,
-                    float* selected, float* grid, int frames,
+ * stretch_silence off): ppg (ppg_rows, frames), `indices` (n) = rows of the
+ * phonemes that ARE stretched (device int32; a row outside [0, ppg_rows) is
+ * not read and turns the grid into NaN); writes selected (frames) = their
+ * summed probability and grid (target_frames), the reference's sequential
+ * fp32 recurrence whose step follows that probability. No selected mass (or
+ * more unselected mass than target frames) yields a non-finite / decreasing
+ * grid exactly as the reference's arithmetic does: callers check.           */
+int pm_stretch_grid(const float* ppg, int ppg_rows, const int* indices,
+                    int n_indices, float* selected, float* grid, int frames,
                     int target_frames, void* stream);
 
 /* ---- FARGAN vocoder engine: replaces promonet.model.FARGAN ---------------

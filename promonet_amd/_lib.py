@@ -72,7 +72,7 @@ SIGNATURES = {
     'pm_fold_weight_norm': (_I, [_P, _P, _P, _I, _I, _P]),
     'pm_to_channels_last': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'pm_grid_sample': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _P]),
-    'pm_stretch_grid': (_I, [_P, _P, _I, _P, _P, _I, _I, _P]),
+    'pm_stretch_grid': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P]),
     'pm_fargan_create': (_I, [_I, _I, _I, ctypes.POINTER(_P)]),
     'pm_fargan_destroy': (_I, [_P]),
     'pm_fargan_load_tensor': (_I, [_P, ctypes.c_char_p, _P, c_int64_p, _I, _P]),

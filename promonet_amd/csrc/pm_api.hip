@@ -1635,15 +1635,16 @@ extern "C" int pm_grid_sample(
 
 // Selective time-stretch grid (edit/core.py:57-110)
 extern "C" int pm_stretch_grid(
-    const float* ppg, const int* indices, int n_indices, float* selected,
-    float* grid, int frames, int target_frames, void* stream) {
+    const float* ppg, int ppg_rows, const int* indices, int n_indices,
+    float* selected, float* grid, int frames, int target_frames,
+    void* stream) {
     if (!ppg || !indices || !selected || !grid)
         return fail(PM_EINVAL, "null argument");
-    if (n_indices < 1 || frames < 1 || target_frames < 1)
+    if (ppg_rows < 1 || n_indices < 1 || frames < 1 || target_frames < 1)
         return fail(PM_EINVAL, "bad stretch-grid arguments");
     StretchArgs a;
     a.ppg = ppg; a.indices = indices; a.selected = selected; a.grid = grid;
-    a.n = n_indices; a.T = frames; a.target = target_frames;
+    a.n = n_indices; a.T = frames; a.target = target_frames; a.P = ppg_rows;
     const size_t bytes = (size_t)frames * sizeof(float);
     const size_t smem = bytes <= 64 * 1024 ? bytes : 0;
     auto kern = pm_stretch_grid_kernel;

@@ -592,10 +592,14 @@ struct StretchArgs {
     const int* indices;    // (n) selected phoneme rows
     float* selected;       // (T) scratch, also returned for inspection
     float* grid;           // (target)
-    int n, T, target;
+    int n, T, target, P;
 };
 
+// (the recurrence is the reference's fp32 step sequence, edit/core.py:94-110:
+// no FMA contraction, so that hundreds of dependent steps round as torch's
+// unfused multiply / add do)
 __global__ __launch_bounds__(256) void pm_stretch_grid_kernel(StretchArgs a) {
+#pragma clang fp contract(off)
     extern __shared__ float sel_lds[];         // T floats when they fit
     __shared__ float red[4];
     const int tid = threadIdx.x;
@@ -603,7 +607,12 @@ __global__ __launch_bounds__(256) void pm_stretch_grid_kernel(StretchArgs a) {
     float partial = 0.f;
     for (int t = tid; t < a.T; t += 256) {
         float s = 0.f;
-        for (int k = 0; k < a.n; ++k) s += a.ppg[(size_t)a.indices[k] * a.T + t];
+        for (int k = 0; k < a.n; ++k) {
+            // a row outside the PPG reads nothing and poisons the grid (NaN)
+            const int row = a.indices[k];
+            s += row >= 0 && row < a.P ? a.ppg[(size_t)row * a.T + t]
+                                       : __builtin_nanf("");
+        }
         a.selected[t] = s;
         if (in_lds) sel_lds[t] = s;
         partial += s;

@@ -64,14 +64,33 @@ def selective(ppg, ratio, indices):
     _lib.require_gpu(ppg)
     lib = _lib.lib()
     ppg = ppg.to(torch.float32).contiguous()
+    if ppg.ndim != 2:
+        raise ValueError('selective grid: ppg must be (phonemes, frames)')
     frames = ppg.shape[-1]
     target = round(frames / ratio)
-    rows = torch.tensor(list(indices), dtype=torch.int32, device=ppg.device)
+    indices = [int(index) for index in indices]
+    if not indices or min(indices) < 0 or max(indices) >= ppg.shape[0]:
+        raise ValueError(
+            f'selective grid: phoneme rows {indices} outside the '
+            f'{ppg.shape[0]}-row PPG')
+    if target < 1:
+        raise ValueError('selective grid: ratio leaves no output frame')
+    rows = torch.tensor(indices, dtype=torch.int32, device=ppg.device)
     selected = torch.empty(frames, device=ppg.device)
     grid = torch.empty(target, device=ppg.device)
     with torch.cuda.device(ppg.device):
         _lib.check(lib.pm_stretch_grid(
-            _lib.ptr(ppg), _lib.ptr(rows, torch.int32), rows.numel(),
-            _lib.ptr(selected), _lib.ptr(grid), frames, target,
+            _lib.ptr(ppg), ppg.shape[0], _lib.ptr(rows, torch.int32),
+            rows.numel(), _lib.ptr(selected), _lib.ptr(grid), frames, target,
             _lib.stream()))
+    # (editing is not the throughput path: one sync buys a loud failure where
+    # the reference's arithmetic silently yields inf / NaN / a grid that runs
+    # backwards - no probability mass on the selected phonemes, or more
+    # unselected mass than output frames)
+    if target > 1 and not bool(
+            (torch.isfinite(grid).all() & (grid[1:] > grid[:-1]).all())):
+        raise ValueError(
+            'selective grid: the selected phonemes carry too little '
+            'probability mass for this ratio (non-finite or non-increasing '
+            'grid)')
     return grid

@@ -221,6 +221,42 @@ __global__ __launch_bounds__(512) void kernB(
     sink_state(s, sink);
 }
 
+
+// ---- C: dependent chains ----------------------------------------------------
+// NACC accumulators in rotation (1 = every MFMA accumulates onto the previous
+// one's result, the N-tile-outer order of a conv with ONE M tile), F scalar
+// fillers behind every MFMA.
+#define CH1(F1) MFMA(a0) F1 MFMA(a0) F1 MFMA(a0) F1 MFMA(a0) F1
+#define CH2(F1) MFMA(a0) F1 MFMA(a1) F1 MFMA(a0) F1 MFMA(a1) F1
+#define FILL0
+#define FILL1 SFMA(x0)
+#define FILL2 SFMA(x0) SFMA(x1)
+#define FILL4 SFMA(x0) SFMA(x1) SFMA(x2) SFMA(x3)
+template <int NACC, int F>
+__global__ __launch_bounds__(512) void kernC(
+    const unsigned* __restrict__ fill, float* sink, unsigned long long* cyc,
+    int reps) {
+    State s;
+    init_state(s, fill);
+    __syncthreads();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int r = 0; r < reps; ++r) {
+#define BODY(CH, FL) asm volatile(CH(FL) CH(FL) CH(FL) CH(FL) : ST_OPS(s) : ST_INS(s));
+        if constexpr (NACC == 1 && F == 0) BODY(CH1, FILL0)
+        if constexpr (NACC == 1 && F == 1) BODY(CH1, FILL1)
+        if constexpr (NACC == 1 && F == 2) BODY(CH1, FILL2)
+        if constexpr (NACC == 1 && F == 4) BODY(CH1, FILL4)
+        if constexpr (NACC == 2 && F == 0) BODY(CH2, FILL0)
+        if constexpr (NACC == 2 && F == 1) BODY(CH2, FILL1)
+        if constexpr (NACC == 2 && F == 2) BODY(CH2, FILL2)
+        if constexpr (NACC == 2 && F == 4) BODY(CH2, FILL4)
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = c1 - c0;
+    sink_state(s, sink);
+}
+
 static unsigned* g_fill; static float* g_sink; static unsigned long long* g_cyc;
 static hipEvent_t e0, e1;
 
@@ -253,12 +289,14 @@ int main(int argc, char** argv) {
     hipMemcpy(g_fill, hf.data(), hf.size() * 4, hipMemcpyHostToDevice);
     hipEventCreate(&e0); hipEventCreate(&e1);
     printf("# overlap2: %s operands\n", zero ? "zero" : "random");
+    const bool only_c = argc > 2 && argv[2][0] == 'C';
     // ---- A ----
     const int reps = 8000;
     // (NM, NV) in units of 16 MFMAs / 64 VALU: MFMA 32 cyc each = 512 per
     // unit; 64 VALU at ~4 cyc = 256 per unit
     struct Shape { int nm16, nv64; } shapes[] = {{8, 8}, {8, 16}, {8, 4}};
     for (auto sh : shapes) {
+        if (only_c) break;
 #define RUNA(MODE, FL, PRIO)                                                 \
         { const char* mname[5] = {"lock", "anti", "mfma only", "valu only", "spec"}; \
           const char* fname[4] = {"scalar fma", "scalar lrelu+cvt", "packed fma", "lrelu+cvt+ds_write"}; \
@@ -281,6 +319,7 @@ int main(int argc, char** argv) {
     // ---- B ----
     const int repsB = 40000;
     for (int threads : {256, 512}) {
+        if (only_c) break;
         const double mf = 256.0 * (threads / 64) * repsB * 16;
 #define RUNB(F, PK)                                                          \
         { char name[128];                                                    \
@@ -292,6 +331,19 @@ int main(int argc, char** argv) {
         RUNB(0, false) RUNB(2, false) RUNB(4, false) RUNB(5, false)
         RUNB(6, false) RUNB(8, false) RUNB(12, false)
         RUNB(2, true) RUNB(4, true) RUNB(8, true)
+    }
+    // ---- C ----
+    {
+        const int threads = 256;      // one wave per SIMD: cycles are exact
+        const double mf = 256.0 * (threads / 64) * repsB * 16;
+#define RUNC(NACC, F)                                                        \
+        { char name[128];                                                    \
+          snprintf(name, sizeof name, "C 1 wave/SIMD  %d accumulator(s) in rotation, %d scalar fillers per MFMA", NACC, F); \
+          timeit(name, mf, [&]() {                                           \
+              hipLaunchKernelGGL((kernC<NACC, F>), dim3(256), dim3(threads), 0, 0, \
+                                 g_fill, g_sink, g_cyc, repsB); }); }
+        RUNC(1, 0) RUNC(1, 1) RUNC(1, 2) RUNC(1, 4)
+        RUNC(2, 0) RUNC(2, 1) RUNC(2, 2) RUNC(2, 4)
     }
     return 0;
 }

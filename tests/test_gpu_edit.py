@@ -105,3 +105,22 @@ def test_edit_then_synthesize_stays_on_device(device, golden_default):
         want_features[3][None], state)
     assert audio.shape == want.shape == (1, 20 * 256)
     assert max_abs(audio, want) < 1e-5
+
+
+def test_selective_grid_rejects_bad_selections(device):
+    """Rows outside the PPG and selections without probability mass fail
+    loudly (the reference's arithmetic yields NaN / inf / a grid that runs
+    backwards, silently)."""
+    import promonet_amd
+    gen = torch.Generator().manual_seed(2)
+    ppg = torch.softmax(torch.randn(40, 50, generator=gen), dim=0).to(device)
+    grid = promonet_amd.edit.grid.selective(ppg, 1.3, [1, 5, 9])
+    assert grid.shape == (round(50 / 1.3),) and bool((grid[1:] > grid[:-1]).all())
+    with pytest.raises(ValueError, match='outside'):
+        promonet_amd.edit.grid.selective(ppg, 1.3, [1, 40])
+    with pytest.raises(ValueError, match='outside'):
+        promonet_amd.edit.grid.selective(ppg[:8], 1.3, [1, 9])
+    empty = ppg.clone()
+    empty[3] = 0.
+    with pytest.raises(ValueError, match='probability mass'):
+        promonet_amd.edit.grid.selective(empty, 1.3, [3])
