@@ -50,7 +50,7 @@ PEAK_HBM_GBS = 8000.
 # sustained register-resident MFMA rate on random operands under the power cap
 # (scripts/micro/mfma_shapes.hip, profiles/r02/micro_mfma_shapes.txt): what an MFMA
 # kernel can reach on this part; reported beside the nominal peak
-SUSTAINED_TFLOPS = {'f16': 1700., 'bf16': 1850.}
+SUSTAINED_TFLOPS = {'f16': 1700., 'bf16': 1900.}
 
 
 def parse_args():
@@ -107,16 +107,17 @@ def synthetic_inputs(batch, frames, seed, device):
         loudness, pitch, periodicity, ppg, speakers, ones, ones.clone())]
 
 
-def cpu_baseline(model_name, budget=40.):
+def cpu_baseline(model_name, budget=90.):
     """The CPU oracle (a port of the reference's op sequence in PyTorch fp32)
-    timed on this host's cores at 8 torch threads and at os.cpu_count()
-    (SURVEY.md section 8(d)): median of 3 runs after a warm-up, on a sample of
-    BASELINE.json config 2's shape (batch 8 x 5 s; FARGAN: batch 2) that a
-    short probe sizes so that each setting gets about budget / 2 seconds. A
-    setting whose 8-frame probe alone takes seconds (all 256 threads of a big
-    host on these small convolutions: oversubscribed, 1000x slower than 8
-    threads) is reported from that probe and not run further, so the bench
-    stays within a few minutes. A reported baseline, not the target."""
+    timed on this host's cores: BASELINE.json config 2
+    in full (batch 8 x 430 frames; FARGAN: batch 2) at 8, 32, 64 and
+    cpu_count / 2 torch threads, median of 3 runs after a warm-up, every setting
+    reported; and config 1 (one 2 s `from_features` call) at the fastest
+    setting. A setting gets budget / 4 seconds: one whose 8-frame probe says the
+    full runs cannot fit (a big host's threads oversubscribed on these small
+    convolutions can be 1000x slower than 8 threads) runs the largest sample
+    that fits, or is reported from the probe, so that the default bench stays
+    within a few minutes. A reported baseline, not the target."""
     sys.path.insert(0, str(ROOT / 'oracle'))
     import restatement as oracle
     if model_name == 'fargan':
@@ -133,7 +134,8 @@ def cpu_baseline(model_name, budget=40.):
     probe_frames = 8
     cpus = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    settings = sorted({min(8, cpus), cpus})
+    settings = sorted({t for t in (8, 32, 64, cpus // 2) if 1 <= t <= cpus}
+                      or {cpus})
     slot = budget / len(settings)
 
     def run(batch, frames):
@@ -156,7 +158,8 @@ def cpu_baseline(model_name, budget=40.):
             probe = run(1, probe_frames)
             rate = probe_frames * hop / probe
             # largest (batch, frames) <= config 2's whose 3 runs fit the slot
-            affordable = rate * (slot - warm - probe) / 3.3 / hop     # frames
+            # (larger batches run faster per sample than the probe predicts)
+            affordable = 2. * rate * (slot - warm - probe) / 3.3 / hop   # frames
             if affordable < 2 * probe_frames:
                 by_threads[threads] = rate
                 sample_by_threads[threads] = \
@@ -168,21 +171,32 @@ def cpu_baseline(model_name, budget=40.):
             by_threads[threads] = batch * frames * hop / statistics.median(times)
             sample_by_threads[threads] = \
                 f'{batch} x {frames} frames, median of 3'
+        threads = max(by_threads, key=by_threads.get)
+        # config 1: one 2 s utterance through the public call's op sequence
+        torch.set_num_threads(threads)
+        short_frames = promonet_amd.convert.seconds_to_frames(2.)
+        run(1, short_frames)
+        short = statistics.median([run(1, short_frames) for _ in range(3)])
     spent = time.perf_counter() - begin
     torch.set_num_threads(default_threads)
-    threads = max(by_threads, key=by_threads.get)
     return {
         'value': by_threads[threads], 'unit': 'samples/s', 'cores': threads,
         'kind': 'port',
         'rtf': by_threads[threads] / promonet_amd.SAMPLE_RATE,
         'samples_per_s_by_threads': by_threads,
         'sample_by_threads': sample_by_threads,
+        'config1_2s_utterance': {
+            'seconds': short, 'threads': threads,
+            'samples_per_s': short_frames * hop / short,
+            'rtf': short_frames * hop / short / promonet_amd.SAMPLE_RATE},
+        'host_cpus': cpus,
         'sample': f'oracle/restatement.py {name} (PyTorch CPU port of the '
                   f'reference op sequence), fp32, at {sorted(by_threads)} torch '
-                  f'threads on {cpus} cpus; per setting a probe sizes the '
-                  f'sample ({sample_by_threads}; config 2 is {full_batch} x '
-                  f'{full_frames}); {spent:.0f} s of CPU work; value = the '
-                  f'faster setting'}
+                  f'threads on {cpus} cpus: config 2 ({full_batch} x '
+                  f'{full_frames} frames) where it fits {slot:.0f} s per '
+                  f'setting ({sample_by_threads}), config 1 (1 x '
+                  f'{short_frames} frames) at {threads} threads; {spent:.0f} s '
+                  f'of CPU work; value = the fastest setting'}
 
 
 def parse_profile(text):
@@ -369,23 +383,43 @@ def main():
             # weights once (they stay L2-resident for all 3 444 steps)
             hbm_bytes = args.batch * frames * (128 * 4 + 256 * 4) + wbytes
             clusters = min(32, args.batch)
+            # What bounds this model is not HBM (0.2 GB of compulsory traffic
+            # per launch) nor the matrix pipe (74 kFLOP per sample) but the
+            # memory system one level up: every cluster member re-streams its
+            # eighth of the weights from its XCD's L2 on each of the 3 444
+            # dependent steps, between 6 inter-workgroup exchanges per step.
+            # `achieved` / `peak` are therefore the aggregate L2 -> CU weight
+            # stream against the L2's measured 34.5 TB/s
+            # (MI355X_MICROARCH.md); the latency floor of the recurrence
+            # stands beside it.
+            l2_gbs = wbytes * steps * clusters / (avg_ms * 1e-3) / 1e9
+            us_per_step = avg_ms * 1e3 / steps
+            # per sub-frame step: 13 matrix-slice phases (1.1 us each at
+            # least: two barriers, an LDS reduction, one L2 round trip) and 6
+            # tagged-granule exchanges (1.3 us for a vector, 2.3 us for 8 x 256
+            # partial sums) - profiles/r02/timeline_fargan_ticks_x10.txt
+            floor_us = 13 * 1.1 + 2 * 1.3 + 4 * 2.3
             result['roofline'] = {
                 'kernel': 'pm_fargan_cluster_kernel',
-                'bound': 'hbm',
-                'achieved': hbm_bytes / (avg_ms * 1e-3) / 1e9,
-                'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                'frac': hbm_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                'bound': 'hbm', 'level': 'l2 (weights re-streamed per step)',
+                'achieved': l2_gbs,
+                'peak': 34500., 'unit': 'GB/s',
+                'frac': l2_gbs / 34500.,
                 'traffic': None,
                 'avg_launch_ms': avg_ms,
                 'algorithmic_bytes_per_launch': hbm_bytes,
-                'note': 'latency-bound recurrence, neither HBM nor MFMA: '
-                        'see latency_model',
+                'hbm_gbs': hbm_bytes / (avg_ms * 1e-3) / 1e9,
+                'note': 'latency-bound recurrence: see latency_model; HBM '
+                        'itself carries only hbm_gbs',
                 'latency_model': {
                     'dependent_steps': steps,
-                    'us_per_step': avg_ms * 1e3 / steps,
-                    'l2_weight_stream_gbs':
-                        wbytes * steps * clusters / (avg_ms * 1e-3) / 1e9,
-                    'l2_peak_gbs': 34500.,
+                    'us_per_step': us_per_step,
+                    'per_cu_l2_stream_gbs': l2_gbs / (clusters * 8),
+                    'per_cu_l2_peak_gbs': 34500. / 256,
+                    'exchanges_per_step': 6,
+                    'matrix_slices_per_step': 13,
+                    'floor_us_per_step': floor_us,
+                    'frac_of_latency_floor': floor_us / us_per_step,
                     'tflops': per_gpu * FARGAN_FLOP_PER_SAMPLE / 1e12}}
         else:
             profile = parse_profile(
@@ -420,6 +454,10 @@ def main():
                 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_TFLOPS[args.dtype],
                 'traffic': traffic,
+                'traffic_source': (
+                    'profiles/traffic.json: rocprofv3 PMC of this build '
+                    '(FETCH_SIZE x 2 + WRITE_SIZE, separate passes), not '
+                    're-measured in this run' if traffic else None),
                 'sustained_peak': SUSTAINED_TFLOPS.get(args.dtype),
                 'frac_of_sustained_peak': (
                     achieved / SUSTAINED_TFLOPS[args.dtype]

@@ -38,6 +38,7 @@ extern "C" {
 #define PM_ESTATE (-2)      /* call order (e.g. forward before finalize)  */
 #define PM_EHIP (-3)        /* a HIP runtime call failed                   */
 #define PM_ENOMEM (-4)      /* workspace too small / allocation failed     */
+#define PM_ETIMEOUT (-5)    /* a bounded inter-workgroup wait gave up      */
 
 /* MFMA operand type (accumulation is always fp32; activations between
  * kernels are always fp32 in HBM) */
@@ -316,7 +317,9 @@ int pm_fargan_forward_ragged(pm_fargan_t h, const float* features,
  * 1 force the latter, 2 force clusters.                                     */
 int pm_fargan_set_mode(pm_fargan_t h, int mode);
 /* Debug / safety: synchronise and report whether an inter-workgroup exchange
- * of the last forward on `workspace` timed out (never expected).            */
+ * of the last forward on `workspace` timed out: PM_ETIMEOUT (never expected
+ * on a GPU this process has to itself; the audio of that forward is invalid
+ * and the caller re-runs, e.g. after pm_fargan_set_mode(h, 1)).             */
 int pm_fargan_check(pm_fargan_t h, int batch, int frames, void* workspace,
                     void* stream);
 

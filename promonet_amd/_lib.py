@@ -119,10 +119,20 @@ def lib():
     return _lib
 
 
+PM_ETIMEOUT = -5
+
+
+class LibraryError(RuntimeError):
+    """A non-zero status of the C ABI; `.code` is the PM_E* value."""
+
+    def __init__(self, code, message):
+        super().__init__(f'libpromonet_hip error {code}: {message}')
+        self.code = code
+
+
 def check(code):
     if code != 0:
-        message = lib().pm_last_error().decode()
-        raise RuntimeError(f'libpromonet_hip error {code}: {message}')
+        raise LibraryError(code, lib().pm_last_error().decode())
 
 
 def ptr(tensor, dtype=torch.float32):

@@ -91,6 +91,10 @@ FARGAN_SUBFRAMES = 4
 DEFAULT_COMPUTE_DTYPE = 'f16'
 COMPUTE_DTYPE = DEFAULT_COMPUTE_DTYPE
 
+# Validate speaker ids that arrive as DEVICE tensors (one sync per call); off:
+# an id outside the embedding table yields NaN audio instead of IndexError
+CHECK_DEVICE_SPEAKERS = False
+
 ASSETS_DIR = Path(__file__).parent / 'assets'
 
 

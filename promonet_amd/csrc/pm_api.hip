@@ -1971,7 +1971,7 @@ extern "C" int pm_fargan_check(
     HIP_TRY(hipMemcpyAsync(&flag, state + (size_t)FG_MAX_CLUSTERS * FG_CSTATE * 4,
                            4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (flag) return fail(PM_EHIP, "FARGAN cluster exchange timed out");
+    if (flag) return fail(PM_ETIMEOUT, "FARGAN cluster exchange timed out");
     return PM_OK;
 }
 

@@ -304,18 +304,25 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
         }
     } else if constexpr (EPI == 4) {
         // log(basis @ magnitude) over each filter's non-zero span, ascending
+        // (two loops, not one pointer select: a pointer that may be LDS or
+        // global is a FLAT pointer, and flat loads cost this epilogue 60 us)
         float* ob = a.out + (size_t)b * a.rows * T + t0;
         for (int idx = tid; idx < a.rows * FR; idx += NT) {
             const int m = idx / FR, c = idx % FR;
             if (c >= nf) continue;
-            const int lo = a.mel_span[3 * m], hi = a.mel_span[3 * m + 1];
-            const float* bv = (mel_in_lds ? melv : a.mel_vals) +
-                              a.mel_span[3 * m + 2];
+            const int lo = a.mel_span[3 * m], n = a.mel_span[3 * m + 1] - lo;
+            const int off = a.mel_span[3 * m + 2];
             const float* sp = ost + lo * OS + c;
             float acc = 0.f;
+            if (mel_in_lds) {
+                const float* bv = melv + off;
 #pragma unroll 4
-            for (int f = 0; f < hi - lo; ++f)
-                acc = fmaf(bv[f], sp[f * OS], acc);
+                for (int f = 0; f < n; ++f) acc = fmaf(bv[f], sp[f * OS], acc);
+            } else {
+                const float* __restrict__ bv = a.mel_vals + off;
+#pragma unroll 4
+                for (int f = 0; f < n; ++f) acc = fmaf(bv[f], sp[f * OS], acc);
+            }
             float v = logf(acc);
             if (a.use_thr) v = fmaxf(v, a.thr);
             ob[(size_t)m * T + c] = v;

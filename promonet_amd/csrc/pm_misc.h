@@ -629,8 +629,12 @@ __global__ __launch_bounds__(256) void pm_stretch_grid_kernel(StretchArgs a) {
     float position = 0.f;
     a.grid[0] = 0.f;
     for (int j = 1; j < a.target; ++j) {
-        int left = (int)floorf(position);
-        left = left < a.T - 1 ? left : a.T - 1;
+        // (a selection without probability mass makes the reference's
+        // arithmetic produce inf / NaN / negative positions: clamp the index -
+        // a NaN compares false - so that nothing is read out of bounds; the
+        // values stay what the reference's formula yields)
+        int left = position >= 0.f
+            ? (int)fminf(floorf(position), (float)(a.T - 1)) : 0;
         float probability;
         if (left + 1 < a.T) {
             const float offset = position - (float)left;

@@ -20,6 +20,11 @@ from .core import attach
 
 class FARGAN(torch.nn.Module):
 
+    # auto mode: calls served by the one-workgroup-per-utterance kernel after
+    # the cluster exchange has timed out twice in a row, before the clusters
+    # are tried again
+    RETRY_AFTER = 16
+
     def __init__(self, num_features, global_channels):
         super().__init__()
         self.num_features = num_features
@@ -28,6 +33,7 @@ class FARGAN(torch.nn.Module):
         self.weight_dtype = promonet_amd.FARGAN_WEIGHT_DTYPE
         self.check_exchange = True
         self.kernel_mode = 0    # 0 auto, 1 workgroup per utterance, 2 clusters
+        self._fallback_calls = 0    # auto mode: calls left on the slow kernel
         for key, tensor in self._initial_state().items():
             attach(self, key, tensor)
         self._engine = None
@@ -183,8 +189,19 @@ class FARGAN(torch.nn.Module):
                 if lengths.shape != (batch,):
                     raise ValueError('lengths must have shape (B,)')
 
+            if self.kernel_mode == 0 and not self.check_exchange:
+                # the clusters' bounded waits are the only safety net of auto
+                # mode: without the check a timed-out exchange would pass as
+                # audio
+                raise RuntimeError(
+                    'FARGAN: check_exchange=False needs an explicit '
+                    'kernel_mode (1 or 2)')
+
             def launch():
-                _lib.check(lib.pm_fargan_set_mode(engine, self.kernel_mode))
+                mode = self.kernel_mode
+                if mode == 0 and self._fallback_calls > 0:
+                    mode = 1
+                _lib.check(lib.pm_fargan_set_mode(engine, mode))
                 if lengths is None:
                     _lib.check(lib.pm_fargan_forward(
                         engine, _lib.ptr(x), int(channels_last), _lib.ptr(g),
@@ -204,22 +221,35 @@ class FARGAN(torch.nn.Module):
                     _lib.check(lib.pm_fargan_check(
                         engine, batch, frames, self._workspace.data_ptr(),
                         _lib.stream()))
+            if self.kernel_mode == 0 and self._fallback_calls > 0:
+                self._fallback_calls -= 1
+                launch()
+                return out
             try:
                 launch()
-            except RuntimeError as error:
+            except _lib.LibraryError as error:
                 # The cluster kernel needs all its workgroups resident at
                 # once; a GPU shared with another process (or CU-masked) can
-                # break that and the bounded exchange gives up. Auto mode
-                # then falls back, for good, to one workgroup per utterance.
-                if self.kernel_mode != 0 or 'timed out' not in str(error):
+                # break that and the bounded exchange gives up (PM_ETIMEOUT,
+                # the audio of that launch is invalid). Auto mode retries the
+                # clusters once - co-tenancy is often transient - and only
+                # then runs this call on the one-workgroup-per-utterance
+                # kernel; the clusters are tried again after RETRY_AFTER calls.
+                if self.kernel_mode != 0 or error.code != _lib.PM_ETIMEOUT:
                     raise
-                import warnings
-                warnings.warn(
-                    'FARGAN cluster exchange timed out (GPU shared or '
-                    'partially masked?); using the one-workgroup-per-'
-                    'utterance kernel from now on')
-                self.kernel_mode = 1
-                launch()
+                try:
+                    launch()
+                except _lib.LibraryError as again:
+                    if again.code != _lib.PM_ETIMEOUT:
+                        raise
+                    import warnings
+                    warnings.warn(
+                        'FARGAN cluster exchange timed out twice (GPU shared '
+                        'or partially masked?); using the one-workgroup-per-'
+                        f'utterance kernel for the next {self.RETRY_AFTER} '
+                        'calls')
+                    self._fallback_calls = self.RETRY_AFTER
+                    launch()
         return out
 
     def remove_weight_norm(self):

@@ -323,9 +323,18 @@ def generate(
 def _check_speakers(speakers):
     """Host-side ids (ints, lists, CPU tensors) are validated like the
     reference's torch.nn.Embedding does (IndexError); device tensors are not
-    read back (no sync) - the kernel turns an out-of-range id into NaN audio."""
+    read back (no sync) - the kernel turns an out-of-range id into NaN audio -
+    unless `promonet_amd.configure(CHECK_DEVICE_SPEAKERS=True)` asks for the
+    reference's behaviour at the price of one device sync per call."""
     if isinstance(speakers, torch.Tensor):
         if speakers.is_cuda:
+            if not promonet_amd.CHECK_DEVICE_SPEAKERS:
+                return
+            bad = (speakers < 0) | (speakers >= promonet_amd.NUM_SPEAKERS)
+            if bool(bad.any()):
+                raise IndexError(
+                    f'speaker {int(speakers[bad][0])} is out of range '
+                    f'[0, {promonet_amd.NUM_SPEAKERS})')
             return
         values = speakers.reshape(-1).tolist()
     elif isinstance(speakers, (list, tuple)):

@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline --sustain 0 $*"
-timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH --steps 3 --warmup 1 > $OUT/stats.log 2>&1
+timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH --steps 20 --warmup 2 > $OUT/stats.log 2>&1
 timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS \
     --kernel-trace -d $OUT/pmc_sq -o sq -- $BENCH --steps 1 --warmup 0 > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE \

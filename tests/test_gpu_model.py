@@ -412,6 +412,16 @@ def test_speaker_ids_are_bounds_checked(device, default_state):
         glob = model.prepare_global_features(ids, ones, ones)
     assert torch.isfinite(glob[0]).all()
     assert torch.isnan(glob[1, :256]).all() and torch.isnan(glob[2, :256]).all()
+    # opt-in: device-side ids validated like the reference (one sync)
+    batch = oracle.synthetic_inputs(2, 8, seed=2)
+    bad_ids = torch.tensor([1, promonet_amd.NUM_SPEAKERS], device=device)
+    promonet_amd.configure(CHECK_DEVICE_SPEAKERS=True)
+    try:
+        with pytest.raises(IndexError):
+            promonet_amd.synthesize.from_features_batched(
+                *batch[:4], speakers=bad_ids, gpu=0)
+    finally:
+        promonet_amd.configure(CHECK_DEVICE_SPEAKERS=False)
 
 
 ###############################################################################
