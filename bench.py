@@ -157,9 +157,29 @@ def cpu_baseline(model_name, budget=90.):
                 continue
             probe = run(1, probe_frames)
             rate = probe_frames * hop / probe
+            # config 2 in full where it fits: the probe under-predicts (a
+            # batch of long utterances runs ~4x faster per sample than 8
+            # frames), so a first full run is the real sizing
+            full_samples = full_batch * full_frames * hop
+            remaining = slot - warm - probe
+            if full_samples / (4. * rate) <= remaining:
+                first = run(full_batch, full_frames)
+                remaining -= first
+                if 3 * first <= remaining:
+                    times = [run(full_batch, full_frames) for _ in range(3)]
+                    by_threads[threads] = \
+                        full_samples / statistics.median(times)
+                    sample_by_threads[threads] = (
+                        f'{full_batch} x {full_frames} frames (config 2), '
+                        'median of 3 after a warm-up')
+                else:
+                    by_threads[threads] = full_samples / first
+                    sample_by_threads[threads] = (
+                        f'{full_batch} x {full_frames} frames (config 2), '
+                        'single run')
+                continue
             # largest (batch, frames) <= config 2's whose 3 runs fit the slot
-            # (larger batches run faster per sample than the probe predicts)
-            affordable = 2. * rate * (slot - warm - probe) / 3.3 / hop   # frames
+            affordable = 2. * rate * remaining / 3.3 / hop        # frames
             if affordable < 2 * probe_frames:
                 by_threads[threads] = rate
                 sample_by_threads[threads] = \

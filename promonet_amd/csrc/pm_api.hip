@@ -1584,7 +1584,9 @@ extern "C" int pm_linear_to_mel(
 
 extern "C" size_t pm_loudness_scratch_bytes(int B, int N) {
     if (B < 1 || N < HOP) return 0;
-    return align256((size_t)B * sizeof(unsigned));
+    // one maximum per FFT workgroup (>= 16 frames each) and utterance
+    const size_t groups = ((size_t)(N / HOP) + 15) / 16;
+    return align256((size_t)B * groups * sizeof(float));
 }
 
 // Two passes over the audio (4 B / sample each) instead of a (B, 513, T) dB
@@ -1602,10 +1604,9 @@ extern "C" int pm_loudness(
     if (B < 1 || N < HOP || scratch_bytes < pm_loudness_scratch_bytes(B, N))
         return fail(PM_ENOMEM, "scratch too small");
     hipStream_t s = (hipStream_t)stream;
-    unsigned* maxbits = (unsigned*)scratch;
-    HIP_TRY(hipMemsetAsync(maxbits, 0, B * sizeof(unsigned), s));
     FftArgs a = {};
-    a.audio = audio; a.out = out; a.B = B; a.N = N; a.maxbits = maxbits;
+    a.audio = audio; a.out = out; a.B = B; a.N = N;
+    a.group_max = (float*)scratch;
     int rc = fft_launch<2>(a, s);
     if (rc) return rc;
     a.weights = a_weights; a.rows = bands;

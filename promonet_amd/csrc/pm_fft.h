@@ -35,12 +35,16 @@
 #define PM_FFT_TAB_W512 1024
 #define PM_FFT_TAB_W1024 (1024 + 1024)
 #define PM_FFT_TAB_FLOATS (1024 + 1024 + 1026)
+// 10 log10(x) = (10 / log2(10)) log2(x): one v_log_f32 (1 ulp) instead of the
+// ~25-instruction log10f, 8 times per lane and frame
+#define PM_DB_PER_LOG2 3.01029995663981195f
 
 struct FftArgs {
     const float* audio;      // (B, N)
     float* out;
     const float* tables;     // PM_FFT_TAB_FLOATS
-    unsigned* maxbits;       // (B) order-preserving bits of the utterance max
+    float* group_max;        // (B, gridDim.x): every workgroup's maximum dB (EPI
+                             // 2 writes it, EPI 3 folds the utterance's row)
     const float* weights;    // EPI 3: (513) A-weights; EPI 4: mel basis (M, 513)
     const int* mel_span;     // EPI 4: pm_mel_csr_kernel's table (lo, hi, offset
                              // per filter, then the non-zero count)
@@ -103,7 +107,7 @@ __device__ __forceinline__ void pm_wave_lds_sync() {
 template <int EPI, int NW, int FPW>
 __host__ __device__ constexpr int pm_fft_smem_bytes() {
     constexpr int FR = NW * FPW;
-    return NW * 576 * 8 + (EPI == 2 ? 0 : PM_FFT_BINS * (FR + 1) * 4) +
+    return NW * 576 * 8 + (EPI == 2 ? 64 : PM_FFT_BINS * (FR + 1) * 4) +
            (EPI == 4 ? PM_FFT_MEL_CAP * 4 : 0);
 }
 
@@ -188,8 +192,23 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
     }
     float local_max = -INFINITY;
     [[maybe_unused]] float floor_db = 0.f;
-    if constexpr (EPI == 3)
-        floor_db = pm_float_from_order_bits(a.maxbits[b]) - a.top_db;
+    if constexpr (EPI == 3) {
+        // the utterance maximum of pass 1 (librosa.amplitude_to_db's top_db
+        // reference): fold this utterance's per-workgroup maxima
+        float m = -INFINITY;
+        const float* gm = a.group_max + (size_t)b * gridDim.x;
+        for (int i = tid; i < (int)gridDim.x; i += NT) m = fmaxf(m, gm[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float* red = reinterpret_cast<float*>(work);   // (free until the first frame)
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+        __syncthreads();
+        floor_db = m - a.top_db;
+    }
 
     float2* wk = work + wave * WS;
 #pragma unroll 1
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
             if constexpr (EPI == 1 || EPI == 4) {
                 ost[k * OS + fl] = sqrtf(pw + 1e-6f);
             } else {
-                const float v = 10.f * log10f(fmaxf(1e-10f, pw));
+                const float v = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, pw));
                 if constexpr (EPI == 2) {
                     local_max = fmaxf(local_max, v);
                 } else {
@@ -263,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
             if constexpr (EPI == 1 || EPI == 4) {
                 ost[512 * OS + fl] = sqrtf(pw + 1e-6f);
             } else {
-                const float v = 10.f * log10f(fmaxf(1e-10f, pw));
+                const float v = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, pw));
                 if constexpr (EPI == 2) {
                     local_max = fmaxf(local_max, v);
                 } else {
@@ -276,11 +295,19 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
     }
 
     if constexpr (EPI == 2) {
+        // one plain store per workgroup (atomics on 32 addresses serialise)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
             local_max = fmaxf(local_max, __shfl_xor(local_max, o, 64));
-        if (lane == 0 && local_max > -INFINITY)
-            atomicMax(a.maxbits + b, pm_float_order_bits(local_max));
+        float* red = reinterpret_cast<float*>(work + NW * WS);   // (64 B behind)
+        if (lane == 0) red[wave] = local_max;
+        __syncthreads();
+        if (tid == 0) {
+            float m = red[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+            a.group_max[(size_t)b * gridDim.x + blockIdx.x] = m;
+        }
         return;
     }
     __syncthreads();
