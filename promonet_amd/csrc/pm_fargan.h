@@ -14,6 +14,7 @@
 #pragma once
 #include "pm_common.h"
 #include <cstddef>
+#include <type_traits>
 
 #ifndef FG_UNROLL
 #define FG_UNROLL 16
@@ -400,7 +401,16 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
 #ifndef FG_INFLIGHT
 #define FG_INFLIGHT 4        // 16-byte weight loads per software-pipeline group
 #endif
+// What runs under the exchanges (see the step loop): level 0 nothing, 1 W_hh h
+// in front of its cell, 2 the balanced schedule over all six exchanges.
+// Batch 32 x 10 s (profiles/r03/fargan/ab_under_exchange.txt): fp32 weights
+// 112-118 / 106-108 / 106-110 ms, f16-stored 91 / 81 / 75 ms at levels 0 / 1 / 2.
+#ifndef FG_UNDER
+#define FG_UNDER(WT) 2
+#endif
 #define FG_SLOTS 416           // granules one member publishes per exchange (max 384 + 32)
+
+struct FgNoOverlap { __device__ __forceinline__ void operator()() const {} };
 
 struct FgCluster {
     unsigned long long* buf;   // [2][FG_UMAX][FG_G][FG_SLOTS] granules
@@ -427,6 +437,11 @@ struct FgLds {
     float part[FG_THREADS];    // reduction buffer P (and the exchanges')
     float part2[FG_THREADS];
     float part3[FG_THREADS];   // reduction buffer Q (see fg_slice)
+    float part4[FG_THREADS];   // reduction buffers R, R': slices run under an
+    float part5[FG_THREADS];   // exchange (see the step loop)
+    float gh[3][96];           // W_hh h of the three GRU cells, computed ahead
+    float gil[3][96];          // W_ih[:, 256:384] [lookback | previous subframe]
+    float skpre[32];           // the skip dense layer without its last input
 };
 static_assert(sizeof(FgLds) % 16 == 0, "16-byte aligned per-utterance state");
 #define FG_OFF(field) (offsetof(FgLds, field) / sizeof(float))
@@ -476,9 +491,13 @@ __device__ __forceinline__ void fg_poll(
 // utterance u's 8 N-long vector; on return field `dst` of every utterance's
 // FgLds holds the whole vector in every member's LDS. Callers guarantee (a
 // barrier since the last read) that nobody still reads dst's old content.
-template <int U, int N>
+// `under` runs between the publish and the poll: work that does not depend on
+// the exchanged data (a slice of the NEXT layers' products of the previous
+// step's state) streams its weights while the granules travel.
+template <int U, int N, class Under = FgNoOverlap>
 __device__ __forceinline__ void fg_exchange(
-    FgCluster& c, const float (&mine)[U], float* lds, int dst, int tid) {
+    FgCluster& c, const float (&mine)[U], float* lds, int dst, int tid,
+    Under under = Under()) {
     c.epoch += 1u;
     const unsigned epoch = c.epoch;
     if (tid < N) {
@@ -489,6 +508,7 @@ __device__ __forceinline__ void fg_exchange(
                 ((unsigned long long)epoch << 32) | __float_as_uint(mine[u]),
                 FG_RLX);
     }
+    under();
     if (tid < FG_G * N) {
         unsigned long long* src[U][1];
         float val[U][1];
@@ -511,10 +531,10 @@ __device__ __forceinline__ void fg_exchange(
 // every member), ext[u] = element tid of the gathered vector.
 // Q = FG_THREADS / R threads share the 8 polls of a row; their partial
 // totals meet in LDS (field `part`, which the caller's fg_slice is done with).
-template <int U, int R, int E>
+template <int U, int R, int E, class Under = FgNoOverlap>
 __device__ __forceinline__ void fg_exchange_sum(
     FgCluster& c, const float (&part)[U], const float (&extra)[U], float* lds,
-    int tid, float (&total)[U], float (&ext)[U]) {
+    int tid, float (&total)[U], float (&ext)[U], Under under = Under()) {
     constexpr int Q = FG_THREADS / R;          // 3 (R 256), 2 (384), 12 (64)
     constexpr int QN = Q > FG_G ? FG_G : Q;    // polling threads per row
     constexpr int NG = (FG_G + QN - 1) / QN;   // granules per polling thread
@@ -537,6 +557,7 @@ __device__ __forceinline__ void fg_exchange_sum(
                 ((unsigned long long)epoch << 32) | __float_as_uint(extra[u]),
                 FG_RLX);
     }
+    under();
     const int row = tid % R, q = tid / R;
     if (q < QN) {
         // members q NG .. q NG + NG - 1 (clamped: a duplicate poll of member
@@ -597,13 +618,41 @@ __device__ __forceinline__ void fg_exchange_sum(
 // (and the partial-sum exchange, which uses P) alternate buffers, so the next
 // writer of a buffer is always at least one barrier - the next slice's own, or
 // the caller's before it touches the next input vector - behind its readers.
-template <class WT, int RW, int RPAD, int U, int KPAD, int PB>
+// DEFER: stop after the partial sums are in the reduction buffer - the caller
+// passes a barrier of its own (an exchange's) and collects with fg_slice_sum.
+// PB 2 / 3 = buffers R / R' (`part4`, `part5`), which only deferred slices use.
+// A K sub-range [k0, k0 + KPAD) of a matrix packed with RPAD rows starts at
+// w + k0 * RPAD (the packing is [k / VEC][row][VEC]).
+template <int PB>
+__host__ __device__ constexpr int fg_pbuf() {
+    return PB == 0 ? FG_OFF(part) : PB == 1 ? FG_OFF(part3)
+         : PB == 2 ? FG_OFF(part4) : FG_OFF(part5);
+}
+
+template <int RW, int U, int PB>
+__device__ __forceinline__ void fg_slice_sum(
+    const float* lds, int tid, float (&sum)[U]) {
+    constexpr int PARTS = FG_THREADS / RW;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float t = 0.f;
+        if (tid < RW) {
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q)
+                t += lds[u * FG_LSTRIDE + fg_pbuf<PB>() + tid + q * RW];
+        }
+        sum[u] = t;
+    }
+}
+
+template <class WT, int RW, int RPAD, int U, int KPAD, int PB,
+          bool DEFER = false>
 __device__ __forceinline__ void fg_slice(
     const WT* __restrict__ w, const float* lds, int xa, int xb, int split,
     int r0, float* ldsw, int tid, float (&sum)[U]) {
     // (with four utterances in lockstep the registers are tight: the
     // per-thread addresses of a slice are computed here, not earlier)
-    if constexpr (U >= 4) asm volatile("" : "+v"(tid));
+    if constexpr (U >= 2) asm volatile("" : "+v"(tid));
     constexpr int VEC = FgVec<WT>::VEC;
     constexpr int PARTS = FG_THREADS / RW;
     constexpr int BLOCKS = KPAD / VEC;
@@ -660,21 +709,13 @@ __device__ __forceinline__ void fg_slice(
             for (int i = 0; i < R; ++i) cur[i] = nxt[i];
         }
     }
-    constexpr int PBUF = PB ? FG_OFF(part3) : FG_OFF(part);
+    constexpr int PBUF = fg_pbuf<PB>();
 #pragma unroll
     for (int u = 0; u < U; ++u)
         ldsw[u * FG_LSTRIDE + PBUF + tid] = acc0[u] + acc1[u];
+    if constexpr (DEFER) return;
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        float t = 0.f;
-        if (tid < RW) {
-#pragma unroll
-            for (int q = 0; q < PARTS; ++q)
-                t += lds[u * FG_LSTRIDE + PBUF + tid + q * RW];
-        }
-        sum[u] = t;
-    }
+    fg_slice_sum<RW, U, PB>(lds, tid, sum);
 }
 
 struct FarganClusterArgs {
@@ -745,6 +786,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             for (int i = tid; i < 3 * FG_HOP; i += NT) (&L[u].hid[0][0])[i] = 0.f;
+            for (int i = tid; i < 3 * 96; i += NT) (&L[u].gh[0][0])[i] = 0.f;   // W_hh 0
             for (int i = tid; i < 2 * FG_SUBIN + 8; i += NT) L[u].subin[i] = 0.f;
             for (int i = tid; i < CPAD; i += NT) L[u].condin[i] = 0.f;
             for (int i = tid; i < 384; i += NT) { L[u].c1[i] = 0.f; L[u].c2[i] = 0.f; }
@@ -830,6 +872,54 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 __syncthreads();
                 FG_STAMP(0);
 
+                // Half of a step's weight stream multiplies inputs that are
+                // known BEFORE the layer in front of them has finished: W_hh h
+                // (the previous step's state), the [lookback | previous
+                // subframe] columns of W_ih, and all of the skip dense layer but
+                // the last GRU's columns. Those products are streamed UNDER the
+                // exchanges - between publishing this member's granules and
+                // polling for the others', partial sums into the reduction
+                // buffers R / R', collected behind the exchange's own barrier -
+                // so that a granule round trip carries ~1 us of weight stream
+                // instead of a poll loop and the slices on the dependency chain
+                // shrink to the columns that really wait. Schedule (level 2):
+                //   E1 fwconv GLU   W_ih[0], W_ih[1] lookback columns
+                //   E2 GRU 0        W_hh[2] h
+                //   E3 GRU 1        W_ih[2] lookback columns, skip [fw|lb|prev]
+                //   E4 GRU 2        skip [g0 | g1]
+                //   E5 skip vector  W_hh[0] h   (for the NEXT step: h is final)
+                //   E6 output       W_hh[1] h   (for the NEXT step)
+                // (level 1: W_hh[n] h under the exchange in front of cell n)
+                constexpr int LVL = FG_UNDER(WT);
+                auto under_hh = [&](int n, auto pb) __attribute__((always_inline)) {
+                    float unused[U];
+                    const int hoff = FG_OFF(hid) + n * FG_HOP;
+                    fg_slice<WT, 96, 768, U, 256, decltype(pb)::value, true>(
+                        w.gru_hh(n), lds, hoff, hoff, 256, g * 96, lds, tid,
+                        unused);
+                };
+                auto under_ih = [&](int n, auto pb) __attribute__((always_inline)) {
+                    float unused[U];
+                    fg_slice<WT, 96, 768, U, 128, decltype(pb)::value, true>(
+                        w.gru_ih(n) + 256 * 768, lds, FG_OFF(skipbuf) + 1024,
+                        FG_OFF(skipbuf) + 1024, 128, g * 96, lds, tid, unused);
+                };
+                // which 0: -> gh[n] (W_hh h), 1: -> gil[n] (W_ih lookback part)
+                auto collect96 = [&](int which, int n, auto pb)
+                    __attribute__((always_inline)) {
+                    float sv[U];
+                    fg_slice_sum<96, U, decltype(pb)::value>(lds, tid, sv);
+                    if (tid < 96) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (which == 0) L[u].gh[n][tid] = sv[u];
+                            else L[u].gil[n][tid] = sv[u];
+                        }
+                    }
+                };
+                using PB2 = std::integral_constant<int, 2>;
+                using PB3 = std::integral_constant<int, 3>;
+
                 // ---- framewise conv (R) + its GLU gate (K): 1 exchange ----
                 fg_slice<WT, 32, 256, U, 520, 0>(w.fwconv(), lds, FG_OFF(subin),
                                               FG_OFF(subin), 520, g * 32, lds,
@@ -845,7 +935,20 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     w.k_fwconv_glu(g), lds, FG_OFF(own),
                     FG_OFF(own), 32, 0, lds, tid, v);
                 FG_STAMP(2);
-                fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                if constexpr (LVL >= 2) {
+                    fg_exchange_sum<U, 256, 32>(
+                        c, v, m, lds, tid, tot, ext, [&]() {
+                            under_ih(0, PB2{}); under_ih(1, PB3{}); });
+                    collect96(1, 0, PB2{});
+                    collect96(1, 1, PB3{});
+                } else if constexpr (LVL == 1) {
+                    fg_exchange_sum<U, 256, 32>(
+                        c, v, m, lds, tid, tot, ext,
+                        [&]() { under_hh(0, PB2{}); });
+                    collect96(0, 0, PB2{});
+                } else {
+                    fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                }
                 FG_STAMP(3);
                 if (tid < 256) {
 #pragma unroll
@@ -859,20 +962,33 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 for (int n = 0; n < 3; ++n) {
                     const int xa = n == 0 ? FG_OFF(skipbuf) + 768
                                           : FG_OFF(skipbuf) + (n - 1) * 256;
-                    const int hoff = FG_OFF(hid) + n * FG_HOP;
                     // this member's 32 units x 3 gates = packed rows g*96 ..
-                    float gi[U], gh[U];
-                    fg_slice<WT, 96, 768, U, 384, 1>(w.gru_ih(n), lds, xa,
-                                                  FG_OFF(skipbuf) + 1024, 256,
-                                                  g * 96, lds, tid, gi);
-                    fg_slice<WT, 96, 768, U, 256, 0>(w.gru_hh(n), lds, hoff, hoff, 256,
-                                                  g * 96, lds, tid, gh);
+                    float gi[U];
+                    if constexpr (LVL >= 2)
+                        fg_slice<WT, 96, 768, U, 256, 1>(
+                            w.gru_ih(n), lds, xa, xa, 256, g * 96, lds, tid, gi);
+                    else
+                        fg_slice<WT, 96, 768, U, 384, 1>(
+                            w.gru_ih(n), lds, xa, FG_OFF(skipbuf) + 1024, 256,
+                            g * 96, lds, tid, gi);
+                    if constexpr (LVL == 0) {
+                        float ghv[U];
+                        const int hoff = FG_OFF(hid) + n * FG_HOP;
+                        fg_slice<WT, 96, 768, U, 256, 0>(
+                            w.gru_hh(n), lds, hoff, hoff, 256, g * 96, lds, tid,
+                            ghv);
+                        if (tid < 96) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) L[u].gh[n][tid] = ghv[u];
+                        }
+                    }
                     FG_STAMP(4 + 4 * n);
                     if (tid < 96) {
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            L[u].part2[tid] = gi[u];
-                            L[u].part2[96 + tid] = gh[u];
+                            L[u].part2[tid] = LVL >= 2
+                                ? gi[u] + L[u].gil[n][tid] : gi[u];
+                            L[u].part2[96 + tid] = L[u].gh[n][tid];
                         }
                     }
                     __syncthreads();
@@ -895,7 +1011,54 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                         w.k_gru_glu(n, g), lds, FG_OFF(own),
                         FG_OFF(own), 32, 0, lds, tid, v);
                     FG_STAMP(6 + 4 * n);
-                    fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                    if (LVL >= 2 && n == 0) {
+                        fg_exchange_sum<U, 256, 32>(
+                            c, v, m, lds, tid, tot, ext,
+                            [&]() { under_hh(2, PB2{}); });
+                        collect96(0, 2, PB2{});
+                    } else if (LVL >= 2 && n == 1) {
+                        // skip dense layer (fargan.py:317-322), columns
+                        // [fwconv | lookback | previous]: known since E1
+                        fg_exchange_sum<U, 256, 32>(
+                            c, v, m, lds, tid, tot, ext, [&]() {
+                                under_ih(2, PB2{});
+                                float unused[U];
+                                fg_slice<WT, 32, 256, U, 384, 3, true>(
+                                    w.skip() + 768 * 256, lds,
+                                    FG_OFF(skipbuf) + 768, FG_OFF(skipbuf) + 768,
+                                    384, g * 32, lds, tid, unused);
+                            });
+                        collect96(1, 2, PB2{});
+                        float sb[U];
+                        fg_slice_sum<32, U, 3>(lds, tid, sb);
+                        if (tid < 32) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) L[u].skpre[tid] = sb[u];
+                        }
+                    } else if (LVL >= 2) {
+                        // ... and columns [g0 | g1]
+                        fg_exchange_sum<U, 256, 32>(
+                            c, v, m, lds, tid, tot, ext, [&]() {
+                                float unused[U];
+                                fg_slice<WT, 32, 256, U, 512, 2, true>(
+                                    w.skip(), lds, FG_OFF(skipbuf),
+                                    FG_OFF(skipbuf), 512, g * 32, lds, tid,
+                                    unused);
+                            });
+                        float sa[U];
+                        fg_slice_sum<32, U, 2>(lds, tid, sa);
+                        if (tid < 32) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) L[u].skpre[tid] += sa[u];
+                        }
+                    } else if (LVL == 1 && n < 2) {
+                        fg_exchange_sum<U, 256, 32>(
+                            c, v, m, lds, tid, tot, ext,
+                            [&]() { under_hh(n + 1, PB2{}); });
+                        collect96(0, n + 1, PB2{});
+                    } else {
+                        fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                    }
                     FG_STAMP(7 + 4 * n);
                     if (tid < 256) {
 #pragma unroll
@@ -910,13 +1073,26 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
 
                 // ---- skip dense (R): vector exchange ----
                 FG_STAMP(16);
-                fg_slice<WT, 32, 256, U, FG_SKIP, 1>(w.skip(), lds, FG_OFF(skipbuf),
-                                                  FG_OFF(skipbuf), FG_SKIP, g * 32,
-                                                  lds, tid, v);
+                if constexpr (LVL >= 2)   // (only the last GRU's columns are left)
+                    fg_slice<WT, 32, 256, U, 256, 1>(
+                        w.skip() + 512 * 256, lds, FG_OFF(skipbuf) + 512,
+                        FG_OFF(skipbuf) + 512, 256, g * 32, lds, tid, v);
+                else
+                    fg_slice<WT, 32, 256, U, FG_SKIP, 1>(
+                        w.skip(), lds, FG_OFF(skipbuf), FG_OFF(skipbuf), FG_SKIP,
+                        g * 32, lds, tid, v);
                 FG_STAMP(17);
 #pragma unroll
-                for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
-                fg_exchange<U, 32>(c, m, lds, FG_OFF(f1), tid);
+                for (int u = 0; u < U; ++u)
+                    m[u] = tanhf(LVL >= 2
+                        ? v[u] + (tid < 32 ? L[u].skpre[tid] : 0.f) : v[u]);
+                if constexpr (LVL >= 2) {
+                    fg_exchange<U, 32>(c, m, lds, FG_OFF(f1), tid,
+                                       [&]() { under_hh(0, PB2{}); });
+                    collect96(0, 0, PB2{});
+                } else {
+                    fg_exchange<U, 32>(c, m, lds, FG_OFF(f1), tid);
+                }
                 FG_STAMP(18);
                 // ---- skip GLU (R) + output layer (K): 1 exchange ----
                 fg_slice<WT, 32, 256, U, 256, 0>(w.skip_glu(), lds, FG_OFF(f1), FG_OFF(f1),
@@ -932,7 +1108,13 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                                             FG_OFF(own), FG_OFF(own), 32, 0, lds,
                                             tid, v);
                 FG_STAMP(20);
-                fg_exchange_sum<U, 64, 0>(c, v, v, lds, tid, tot, ext);
+                if constexpr (LVL >= 2) {
+                    fg_exchange_sum<U, 64, 0>(c, v, v, lds, tid, tot, ext,
+                                              [&]() { under_hh(1, PB2{}); });
+                    collect96(0, 1, PB2{});
+                } else {
+                    fg_exchange_sum<U, 64, 0>(c, v, v, lds, tid, tot, ext);
+                }
                 FG_STAMP(21);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
