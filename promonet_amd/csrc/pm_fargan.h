@@ -399,7 +399,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
 
 #define FG_UMAX 4              // utterances a cluster advances in lockstep
 #ifndef FG_INFLIGHT
-#define FG_INFLIGHT 4        // 16-byte weight loads per software-pipeline group
+#define FG_INFLIGHT 8        // 16-byte weight loads per software-pipeline group
 #endif
 // What runs under the exchanges (see the step loop): level 0 nothing, 1 W_hh h
 // in front of its cell, 2 the balanced schedule over all six exchanges.
