@@ -249,6 +249,15 @@ int pm_debug_timeline(void* dev_buffer);
  * that many segments per utterance, upsample_groups > 0 that many M groups
  * per column tile; 0, 0 restores the heuristics. Process-wide.             */
 int pm_debug_force(int walk_nseg, int upsample_groups);
+/* Test hook: -1 keeps every launcher off the skewed whole-Block walk
+ * (conv_block3_skew_kernel), 1 takes it wherever it fits, 0 restores the
+ * default (the shapes it measured faster on). Process-wide.                 */
+int pm_debug_skew(int mode);
+/* Scratch the skewed whole-Block walk wants BEHIND the 3 x
+ * pm_op_workspace_bytes() of pm_block_cl's workspace for `batch` utterances
+ * (optional: without it the walked / stand-alone kernels run). The engine's
+ * own scratch is part of pm_hifigan_workspace_bytes().                      */
+size_t pm_walk_scratch_bytes(int batch);
 /* torch.nn.utils.weight_norm fold: w = g * v / ||v||, rows x cols        */
 int pm_fold_weight_norm(const float* g, const float* v, float* w, int rows,
                         int cols, void* stream);

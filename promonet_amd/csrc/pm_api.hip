@@ -626,8 +626,15 @@ extern "C" int pm_hifigan_features_cl_channels(pm_hifigan_t h) {
 }
 
 struct Plan {
-    size_t off_feat, off_gbias, off_buf, buf_elems, total;
+    size_t off_feat, off_gbias, off_buf, buf_elems, off_scratch, scratch, total;
 };
+
+// Scratch of the skewed whole-Block walk: one workgroup per (utterance,
+// segment), at most max(B, CUs) of them (pm_launch.h)
+static size_t walk_scratch_bytes(int B) {
+    const int cus = pm_device_cus();
+    return (size_t)std::max(B, cus > 0 ? cus : 256) * PM_SKEW_WG_SCRATCH;
+}
 
 static Plan make_plan(pm_hifigan_t h, int B, int T) {
     Plan p;
@@ -641,7 +648,9 @@ static Plan make_plan(pm_hifigan_t h, int B, int T) {
     p.off_feat = 0;
     p.off_gbias = align256((size_t)B * T * h->cfp * sizeof(float));
     p.off_buf = p.off_gbias + align256((size_t)B * h->c0p * sizeof(float));
-    p.total = p.off_buf + 4 * p.buf_elems * sizeof(float);
+    p.off_scratch = p.off_buf + 4 * p.buf_elems * sizeof(float);
+    p.scratch = walk_scratch_bytes(B);
+    p.total = p.off_scratch + p.scratch;
     return p;
 }
 
@@ -777,6 +786,7 @@ static int forward_impl(
                 }
                 a.B = B; a.L = L; a.mode = j == 0 ? 1 : 2; a.scale = scale;
                 a.lengths = lengths; a.len_scale = rate;
+                a.scratch = base + p.off_scratch; a.scratch_bytes = p.scratch;
                 char label[64];
                 snprintf(label, sizeof(label), "block_c%d_k%d", st.cout, K);
                 hipError_t e = hipSuccess;
@@ -1093,6 +1103,12 @@ extern "C" int pm_block_cl(
         a.w1[n] = p1; a.w2[n] = p2;
         a.dil[n] = dilations[n];
     }
+    // (what the caller hands over beyond the packed weights serves the skewed
+    // walk: pm_walk_scratch_bytes)
+    if (ws_bytes > 3 * per) {
+        a.scratch = (char*)ws + 3 * per;
+        a.scratch_bytes = ws_bytes - 3 * per;
+    }
     hipError_t e = launch_block3(dtype, Cp, K, a, s);
     if (e == hipErrorNotSupported)
         return fail(PM_EINVAL, "no whole-Block kernel for this shape");
@@ -1253,6 +1269,22 @@ extern "C" int pm_debug_force(int walk_nseg, int upsample_groups) {
     pm_force().walk_nseg = walk_nseg;
     pm_force().upsample_groups = upsample_groups;
     return PM_OK;
+}
+
+// Test hook: -1 keeps the launchers off the skewed whole-Block walk, 1 takes
+// it wherever it fits, 0 restores the default (the shapes it measured faster
+// on, when scratch was handed over).
+extern "C" int pm_debug_skew(int mode) {
+    if (mode < -1 || mode > 1) return fail(PM_EINVAL, "mode is -1, 0 or 1");
+    pm_force().skew = mode;
+    return PM_OK;
+}
+
+// Scratch bytes the skewed whole-Block walk wants behind the workspace of
+// pm_block_cl for a batch of B utterances (optional: without it the walked
+// or stand-alone kernels run).
+extern "C" size_t pm_walk_scratch_bytes(int B) {
+    return B < 1 ? 0 : walk_scratch_bytes(B);
 }
 
 extern "C" int pm_fold_weight_norm(

@@ -124,6 +124,9 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // in order and every group waits on younger A loads) and whose VALU / LDS
 // writes should overlap the partner wave's MFMAs rather than sit between two
 // barriers - the fp32 -> operand conversion + LDS write of the next chunk.
+#ifndef PM_BDEPTH
+#define PM_BDEPTH 2     // B fragments in flight: this many k16 steps' worth
+#endif
 template <class ET, int KT, int KC, int MTW, int NTW, int G, int S,
           class Hook = NoHook>
 __device__ __forceinline__ void mma_taps(
@@ -133,16 +136,24 @@ __device__ __forceinline__ void mma_taps(
     const typename ET::frag_t* __restrict__ wnext, Hook mid = Hook()) {
     typedef typename ET::frag_t frag_t;
     constexpr int NS = KT * KC;
+    constexpr int BD = PM_BDEPTH;
     static_assert(NS % G == 0, "group size must divide the step count");
+    static_assert(NS >= BD, "fewer steps than B buffers");
     frag_t abuf[2][G][MTW];   // A (weights): one GROUP ahead, from L2
-    frag_t bbuf[2][NTW];      // B (activations): one STEP ahead, from LDS
+    frag_t bbuf[BD][NTW];     // B (activations): BD - 1 STEPS ahead, from LDS
+    auto load_b = [&](frag_t (&dst)[NTW], const int step) {
+        const int j = step / KC, kc = step % KC;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            dst[nt] = *reinterpret_cast<const frag_t*>(
+                bptr + nt * 32 * S + j * tap_bytes + kc * 16 * ET::ESZ);
+    };
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) abuf[0][g][mt] = first[g][mt];
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-        bbuf[0][nt] = *reinterpret_cast<const frag_t*>(bptr + nt * 32 * S);
+    for (int s = 0; s < BD - 1; ++s) load_b(bbuf[s], s);
 #pragma unroll
     for (int g0 = 0; g0 < NS; g0 += G) {
         const int cur = (g0 / G) & 1;
@@ -169,17 +180,14 @@ __device__ __forceinline__ void mma_taps(
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int step = g0 + g;
-            const int cb = step & 1;
-            if (step + 1 < NS) {
-                const int j = (step + 1) / KC, kc = (step + 1) % KC;
+            const int cb = step % BD;
+            if (step + BD - 1 < NS) {
+#if defined(PM_TUNING) && defined(PM_ABLATE_B)   // timing experiment only: no LDS operand stream
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
-#if defined(PM_TUNING) && defined(PM_ABLATE_B)   // timing experiment only: no LDS operand stream
-                    bbuf[cb ^ 1][nt] = bbuf[cb][nt];
+                    bbuf[(step + BD - 1) % BD][nt] = bbuf[cb][nt];
 #else
-                    bbuf[cb ^ 1][nt] = *reinterpret_cast<const frag_t*>(
-                        bptr + nt * 32 * S + j * tap_bytes +
-                        kc * 16 * ET::ESZ);
+                load_b(bbuf[(step + BD - 1) % BD], step + BD - 1);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -983,6 +991,8 @@ struct Block3Args {
     int ntiles, halo, TL;
     const int* lengths;  // (B) valid frames per utterance or null
     int len_scale;
+    char* scratch;       // device scratch for the skewed walk, or null
+    size_t scratch_bytes;
     PM_TIMELINE_FIELD    // debug stamps (tuning builds)
 };
 
@@ -1661,4 +1671,501 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_walk_kernel(
         own += w.store_n;
         left = 1;
     }
+}
+
+// ---------------------------------------------------------------------------
+// A whole Block, walked with SKEWED windows: no column is computed twice.
+//
+// The walked kernels above keep the windows of all six layers aligned, so the
+// columns that lack right context (a.halo of them per tile) are recomputed by
+// the next tile: 12 ... 31 % of the MFMA work. Here iteration i works on the
+// window [c0 - 32 i, c0 - 32 i + NC): its input ends 32 columns further right
+// than its output, which covers the right context of both of its convolutions
+// (H2 (d + 1) <= 30). A step advances every window by exactly NC columns.
+//   * the fp32 trunk stays in the accumulator layout; between two iterations
+//     it moves one 32-column tile to the right in the register file (the
+//     window moves 32 columns left): within a wave by register moves, across
+//     waves through a 4 KB slot of L2-resident scratch per wave, written in
+//     epilogue 2 and read back under the next conv1 (the first tile of the
+//     workgroup comes from the slot its last wave wrote one step earlier);
+//   * the left context of a layer's input - the last 32 + H2 (d - 1) columns
+//     of `a`, the last 2 H2 of `t` - is what the previous step left behind;
+//     it travels through scratch as well (the LDS holds the two operand tiles
+//     and nothing else);
+//   * conv1 of iteration 0 needs lrelu(x) H2 (d_0 + 1) columns beyond the
+//     trunk's window: a 32-column strip is staged next to it.
+// Same arithmetic per column as every other tiling of the Block.
+// ---------------------------------------------------------------------------
+struct Block3SkewArgs {
+    Block3Args a;
+    int nseg;               // segments per utterance
+    int wg_scratch;         // bytes of scratch per workgroup
+    char* scratch;
+};
+
+template <class ET, int C, int K, int WM, int WN, int NTW>
+struct SkewGeom {
+    static constexpr int NC = WN * NTW * 32;
+    static constexpr int H2 = (K - 1) / 2;
+    static constexpr int AL = 4 * H2;            // left margin of `a` (d <= 5)
+    static constexpr int S = C * ET::ESZ + 16;
+    static constexpr int RA = AL + 32 + NC;      // rows of `a`
+    static constexpr int RT = NC + 2 * H2;       // rows of `t`
+    static constexpr int MTW = (C / 32) / WM;
+    static constexpr int NW = WM * WN;
+    static constexpr int TB = MTW * 4096;        // a wave's boundary tiles, fp32
+    static constexpr int CA = 32 + 4 * H2;       // rows of an `a` carry, at most
+    static constexpr int OFF_AC = 2 * 2 * NW * TB;   // [parity][iteration][wave]
+    static constexpr int OFF_TC = OFF_AC + 3 * CA * S;
+    static constexpr int SCRATCH = (OFF_TC + 3 * 2 * H2 * S + 255) & ~255;
+    static constexpr int SMEM = (RA + RT) * S;
+};
+
+template <class ET, int C, int K, int WM, int WN, int NTW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
+    Block3SkewArgs p) {
+    typedef SkewGeom<ET, C, K, WM, WN, NTW> GE;
+    typedef typename ET::frag_t frag_t;
+    constexpr int CH = C < 64 ? C : 64;
+    constexpr int NCH = C / CH;
+    constexpr int KC = CH / 16;
+    constexpr int MTW = GE::MTW;
+    constexpr int NC = GE::NC;
+    constexpr int NT = WM * WN * 64;
+    constexpr int H2 = GE::H2;
+    constexpr int AL = GE::AL;
+    constexpr int S = GE::S;
+    constexpr int QS = S / 16;
+    constexpr int G = (ET::ESZ == 4) ? 2 : KC;
+    constexpr int W_CHUNK = K * KC * 64;
+    constexpr int W_BIAS = NCH * W_CHUNK;
+    constexpr int W_MT_STRIDE = W_BIAS + 64;
+    constexpr int AUX = 16;        // sc1: served by the L2, never by this CU's L1
+    static_assert(NTW >= 2, "the trunk shift needs two tiles per wave");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* abuf = smem;
+    char* tbuf = smem + GE::RA * S;
+
+    const Block3Args& a = p.a;
+    const int H = a.halo;
+    const int b = blockIdx.x / p.nseg, seg = blockIdx.x % p.nseg;
+    const int L = a.lengths ? min(a.lengths[b] * a.len_scale, a.L) : a.L;
+    const int per = (((L + p.nseg - 1) / p.nseg) + 31) & ~31;
+    const int s0 = seg * per;
+    const int e0 = min(L, s0 + per);
+    if (s0 >= e0) return;
+    const Block3SkewArgs __attribute__((address_space(4)))* karg =
+        (const Block3SkewArgs __attribute__((address_space(4)))*)
+            __builtin_amdgcn_kernarg_segment_ptr();
+    const int niter = a.niter;
+    const int skew = 32 * (niter - 1);
+
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.scratch + (size_t)blockIdx.x * p.wg_scratch, 0, GE::SCRATCH,
+        0x00020000);
+    const float* __restrict__ xb = a.x + (size_t)b * a.L * C;
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m_first = wm * MTW * 32;
+    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    // Everything derived from the thread id is recomputed where it is used,
+    // from an opaque copy: hoisted out of the walk it would be carried - i.e.
+    // spilled - across the MFMA loops (trunk, the requested x and the operand
+    // pipeline take 210 of the 256 registers)
+    auto fresh_tid = []() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    auto col_offset = [&](int t) {
+        return (wn * NTW * 32 + (t & 31)) * S + ((t >> 5) & 1) * 8 * ET::ESZ;
+    };
+    auto stream_of = [&](const void* w, int t) {
+        return reinterpret_cast<const frag_t*>(w) +
+               (size_t)(wm * MTW) * W_MT_STRIDE + (t & 63);
+    };
+
+    floatx16 trunk[MTW][NTW];
+    floatx16 acc[MTW][NTW];
+    frag_t bf[MTW];
+    frag_t afirst[G][MTW];
+
+    // LDS rows -> scratch (a layer's last columns, for the next step)
+    auto rows_out = [&](int tid, const char* src, int rows, unsigned soff) {
+        const int n = rows * QS;
+        for (int i = tid; i < n; i += NT) {
+            const float4 v = reinterpret_cast<const float4*>(src)[i];
+            const pm_u4 u = {__float_as_uint(v.x), __float_as_uint(v.y),
+                             __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u, srsrc, soff + (unsigned)i * 16, 0, 0);
+        }
+    };
+    // scratch -> registers (issued early) -> LDS rows (a layer's left margin);
+    // `dead` pushes the offsets out of range - zeros - on a segment's first step
+    constexpr int Q = C / 4;
+    constexpr int CIN = (GE::CA * QS + NT - 1) / NT;     // an `a` carry
+    constexpr int TIN = (2 * H2 * QS + NT - 1) / NT;     // a `t` carry
+    constexpr int SIT = (32 * Q + NT - 1) / NT;          // the x strip (fp32)
+    constexpr int PRE = CIN > SIT ? CIN : SIT;
+    auto rows_request = [&](int tid, auto& r, int rows, unsigned soff,
+                            unsigned dead) {
+        constexpr int N = sizeof(r) / sizeof(r[0]);
+#pragma unroll
+        for (int it = 0; it < N; ++it) {
+            const int i = tid + it * NT;
+            r[it] = __builtin_amdgcn_raw_buffer_load_b128(
+                srsrc, (i < rows * QS ? soff + (unsigned)i * 16 : 0x40000000u) + dead,
+                0, AUX);
+        }
+    };
+    auto rows_in = [&](int tid, char* dst, const auto& r, int rows) {
+        constexpr int N = sizeof(r) / sizeof(r[0]);
+#pragma unroll
+        for (int it = 0; it < N; ++it) {
+            const int i = tid + it * NT;
+            if (i < rows * QS)
+                reinterpret_cast<pm_u4*>(dst)[i] = r[it];
+        }
+    };
+
+#ifdef PM_TUNING
+    // phase totals of wave 0 (shader clocks): 0 stage, 1 conv1, 2 epilogue 1,
+    // 3 its barrier, 4 conv2, 5 epilogue 2, 6 store drain, 7 its barrier,
+    // 8 output store, 9 steps
+    unsigned long long ph[10] = {};
+    unsigned long long last = __builtin_amdgcn_s_memtime();
+#define PM_SKEW_MARK(k)                                                       \
+    do {                                                                      \
+        const unsigned long long now = __builtin_amdgcn_s_memtime();          \
+        ph[k] += now - last; last = now;                                      \
+    } while (0)
+#else
+#define PM_SKEW_MARK(k) ((void)0)
+#endif
+    // the 32 columns of x behind a step's window (fp32, all channels)
+    auto strip_request = [&](int tid, pm_u4 (&r)[PRE], int c_first) {
+        const int lo = max(c_first, 0);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xb) + (size_t)lo * C, 0,
+            max(min(L, c_first + 32) - lo, 0) * C * 4, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int idx = tid + it * NT;
+            r[it] = __builtin_amdgcn_raw_buffer_load_b128(
+                rsrc, (unsigned)(((c_first - lo) * C + idx * 4) * 4), 0, 0);
+        }
+    };
+    // requested under a conv2: the next iteration's `a` carry, or (last
+    // iteration) the next step's x strip
+    pm_u4 pre[PRE];
+    int left = 0, par = 0;
+#pragma unroll 1
+    // (a segment's first step has no t on the first H2 columns of iteration
+    // 0's window: garbage inside the warm-up columns of a later segment; at the
+    // utterance start the walk begins one tile early, where they are padding)
+    for (int c0 = s0 == 0 ? -32 : s0 - H; c0 - skew < e0;
+         c0 += NC, left = 1, par ^= 1) {
+        const unsigned dead = left ? 0u : 0x40000000u;
+        {
+            const frag_t* w1 = stream_of(karg->a.w1[0], fresh_tid());
+            load_bias_frags<ET, MTW>(bf, w1 + W_BIAS, W_MT_STRIDE);
+            load_a_group<ET, MTW, G>(afirst, w1, W_MT_STRIDE);
+        }
+        // ---- trunk <- x on [c0, c0 + NC), a_0 = lrelu(x) on [c0, c0 + NC + 32)
+        {
+            const int tid = fresh_tid();
+            const int ln = tid & 31, lh = (tid >> 5) & 1;
+            const int x_lo = max(c0, 0);
+            const __amdgpu_buffer_rsrc_t xrsrc =
+                __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(xb) + (size_t)x_lo * C, 0,
+                    max(min(L, c0 + NC + 32) - x_lo, 0) * C * 4, 0x00020000);
+            // (a segment's first step: the strip first, its round trip runs
+            // under the tile stores; later steps requested it under conv2)
+            if (!left) strip_request(tid, pre, c0 + NC);
+            if (left) {
+                // requested by the previous step under its last conv2
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) trunk[mt][nt] = acc[mt][nt];
+            } else {
+                const unsigned voff0 = (unsigned)(
+                    ((c0 - x_lo + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const unsigned voff =
+                            voff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const pm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                xrsrc, voff + g4 * 32, 0, 0);
+                            trunk[mt][nt][4 * g4 + 0] = __uint_as_float(v.x);
+                            trunk[mt][nt][4 * g4 + 1] = __uint_as_float(v.y);
+                            trunk[mt][nt][4 * g4 + 2] = __uint_as_float(v.z);
+                            trunk[mt][nt][4 * g4 + 3] = __uint_as_float(v.w);
+                        }
+                    }
+            }
+            const int d0 = karg->a.dil[0];
+            pm_u4 cin[CIN] = {};
+            if (d0 > 1) rows_request(tid, cin, H2 * (d0 - 1), GE::OFF_AC, dead);
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int col = (wn * NTW + nt) * 32 + ln;
+                    store_tile_lrelu_impl<ET, false>(
+                        abuf + (AL + col) * S, m_first + mt * 32, trunk[mt][nt],
+                        false, lh);
+                }
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) {
+                const int idx = tid + it * NT;
+                const int r = idx / Q, q = idx % Q;
+                if (idx < 32 * Q)
+                    ET::store4(abuf + (AL + NC + r) * S + q * 4 * ET::ESZ,
+                               pm_lrelu4(make_float4(
+                                   __uint_as_float(pre[it].x),
+                                   __uint_as_float(pre[it].y),
+                                   __uint_as_float(pre[it].z),
+                                   __uint_as_float(pre[it].w))));
+            }
+            if (d0 > 1)
+                rows_in(tid, abuf + (AL + H2 - H2 * d0) * S, cin, H2 * (d0 - 1));
+        }
+        pm_block_sync();
+        PM_SKEW_MARK(0);
+
+#pragma unroll 1
+        for (int it = 0; it < niter; ++it) {
+            const int d = karg->a.dil[it];
+            const int o = c0 - 32 * it;           // time of the window's column 0
+            const bool more = it + 1 < niter;
+
+            // ---- conv1 (dilation d): t on [o + H2, o + H2 + NC) ----
+            bias_start<ET, MTW, NTW>(acc, bf);
+            // the previous step's last 2 H2 columns of t: requested here,
+            // written behind the tiles of epilogue 1
+            pm_u4 tcin[TIN];
+            {
+                const int t1 = fresh_tid();
+                rows_request(t1, tcin, 2 * H2, GE::OFF_TC + it * 2 * H2 * S, dead);
+                const frag_t* w1 = stream_of(karg->a.w1[it], t1);
+                const frag_t* w2 = stream_of(karg->a.w2[it], t1);
+                const int col_off = col_offset(t1);
+#pragma unroll 1
+                for (int c = 0; c < NCH; ++c)
+                    mma_taps<ET, K, KC, MTW, NTW, G, S>(
+                        acc, abuf + (AL + H2 - H2 * d) * S + col_off + c * CH * ET::ESZ,
+                        d * S, w1 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
+                        c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
+            }
+            PM_SKEW_MARK(1);
+            const int tid = fresh_tid();
+            const int ln = tid & 31, lh = (tid >> 5) & 1;
+            load_bias_frags<ET, MTW>(
+                bf, stream_of(karg->a.w2[it], tid) + W_BIAS, W_MT_STRIDE);
+            // `a` is stable until epilogue 2: what the next step needs of it
+            {
+                const int rows = (it ? 32 : 0) + H2 * (d - 1);
+                rows_out(tid, abuf + (AL + NC + H2 - H2 * d) * S, rows,
+                         GE::OFF_AC + it * GE::CA * S);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int col_first = (wn * NTW + nt) * 32;
+                    store_tile_lrelu<ET>(
+                        tbuf + (2 * H2 + col_first + ln) * S, m_first + mt * 32,
+                        acc[mt][nt], o + H2 + col_first, L, ln, lh);
+                    // x of the next step, into the (now dead) conv1
+                    // accumulators: the round trip runs under the last conv2
+                    if (!more) {
+                        const int cn = c0 + NC;           // (>= 0)
+                        const __amdgpu_buffer_rsrc_t nrsrc =
+                            __builtin_amdgcn_make_buffer_rsrc(
+                                const_cast<float*>(xb) + (size_t)cn * C, 0,
+                                (cn - skew < e0 ? max(min(L, cn + NC) - cn, 0) : 0) *
+                                    C * 4, 0x00020000);
+                        const unsigned voff = (unsigned)(
+                            ((col_first + ln) * C + m_first + mt * 32 + 4 * lh) * 4);
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const pm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                nrsrc, voff + g4 * 32, 0, 0);
+                            acc[mt][nt][4 * g4 + 0] = __uint_as_float(v.x);
+                            acc[mt][nt][4 * g4 + 1] = __uint_as_float(v.y);
+                            acc[mt][nt][4 * g4 + 2] = __uint_as_float(v.z);
+                            acc[mt][nt][4 * g4 + 3] = __uint_as_float(v.w);
+                        }
+                    }
+                }
+            rows_in(tid, tbuf, tcin, 2 * H2);
+            // ---- conv2 (dilation 1) onto the trunk, in place ----
+            bias_add<ET, MTW, NTW>(trunk, bf);
+            PM_SKEW_MARK(2);
+            pm_block_sync();
+            PM_SKEW_MARK(3);
+            {
+                const int t2 = fresh_tid();
+                if (more)
+                    rows_request(t2, pre, 32 + H2 * (karg->a.dil[it + 1] - 1),
+                                 GE::OFF_AC + (it + 1) * GE::CA * S, dead);
+                else if (c0 + NC - skew < e0)
+                    strip_request(t2, pre, c0 + 2 * NC);
+                const frag_t* w2 = stream_of(karg->a.w2[it], t2);
+                const frag_t* w1n =
+                    stream_of(karg->a.w1[more ? it + 1 : it], t2);
+                const int col_off = col_offset(t2);
+#pragma unroll 1
+                for (int c = 0; c < NCH; ++c)
+                    mma_taps<ET, K, KC, MTW, NTW, G, S>(
+                        trunk, tbuf + col_off + c * CH * ET::ESZ, S,
+                        w2 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
+                        c + 1 < NCH ? w2 + (size_t)(c + 1) * W_CHUNK
+                                    : (more ? w1n : nullptr));
+            }
+            PM_SKEW_MARK(4);
+            const int te = fresh_tid();
+            const int ln2 = te & 31, lh2 = (te >> 5) & 1;
+            const unsigned lane_slot = (unsigned)((te & 63) * 16);
+            if (more)
+                load_bias_frags<ET, MTW>(
+                    bf, stream_of(karg->a.w1[it + 1], te) + W_BIAS, W_MT_STRIDE);
+            // `t` is stable until the next epilogue 1
+            rows_out(te, tbuf + NC * S, 2 * H2, GE::OFF_TC + it * 2 * H2 * S);
+            if (more) {
+                // the wave's last tile leaves for its right-hand neighbour
+                const unsigned xo =
+                    (unsigned)(((par * 2 + it) * GE::NW + wave) * GE::TB) +
+                    lane_slot;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const floatx16& v = trunk[mt][NTW - 1];
+                        const pm_u4 u = {__float_as_uint(v[4 * g4 + 0]),
+                                         __float_as_uint(v[4 * g4 + 1]),
+                                         __float_as_uint(v[4 * g4 + 2]),
+                                         __float_as_uint(v[4 * g4 + 3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            u, srsrc, xo + mt * 4096 + g4 * 1024, 0, 0);
+                    }
+                const int dn = karg->a.dil[it + 1];
+                // a_{it+1} = lrelu(trunk) on [o, o + NC): rows AL + 32 ... of
+                // the next iteration's frame
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const int col_first = (wn * NTW + nt) * 32;
+                        store_tile_lrelu<ET>(
+                            abuf + (AL + 32 + col_first + ln2) * S,
+                            m_first + mt * 32, trunk[mt][nt], o + col_first, L,
+                            ln2, lh2);
+                    }
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = NTW - 1; nt > 0; --nt)
+                        trunk[mt][nt] = trunk[mt][nt - 1];
+                rows_in(te, abuf + (AL + H2 - H2 * dn) * S, pre,
+                        32 + H2 * (dn - 1));
+                // the slots and carries written above are read by other waves
+                // behind this barrier
+                PM_SKEW_MARK(5);
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+                PM_SKEW_MARK(6);
+                pm_block_sync();
+                PM_SKEW_MARK(7);
+                const unsigned xi = wn > 0
+                    ? (unsigned)(((par * 2 + it) * GE::NW + wave - 1) * GE::TB)
+                    : (unsigned)((((par ^ 1) * 2 + it) * GE::NW + wave + WN - 1) *
+                                 GE::TB) + dead;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const pm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                            srsrc, xi + lane_slot + mt * 4096 + g4 * 1024, 0,
+                            AUX);
+                        trunk[mt][0][4 * g4 + 0] = __uint_as_float(v.x);
+                        trunk[mt][0][4 * g4 + 1] = __uint_as_float(v.y);
+                        trunk[mt][0][4 * g4 + 2] = __uint_as_float(v.z);
+                        trunk[mt][0][4 * g4 + 3] = __uint_as_float(v.w);
+                    }
+            }
+        }
+
+        // ---- store [o, o + NC) of the last iteration, clipped to the
+        // segment: out-of-range rows are dropped by the descriptor ----
+        const int o = c0 - skew;
+        const int ts = fresh_tid();
+        const int ln = ts & 31, lh = (ts >> 5) & 1;
+        const int own_first = max(s0, o);
+        const int own_n = min(e0, o + NC) - own_first;
+        const float scale = a.scale;
+        const int mode = a.mode;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+            a.out + ((size_t)b * a.L + own_first) * C, 0,
+            max(own_n, 0) * C * 4, 0x00020000);
+        const unsigned ovoff0 = (unsigned)(
+            ((o - own_first + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
+        // (MRF accumulation: the reads of `out` go out two tiles at a time
+        // before the first store of the pair - one round trip per pair)
+        const float sc = mode == 0 ? 1.f : scale;
+#pragma unroll
+        for (int t0 = 0; t0 < MTW * NTW; t0 += 2) {
+            pm_u4 old[2][4] = {};
+            if (mode == 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (t0 + i >= MTW * NTW) break;
+                    const int mt = (t0 + i) / NTW, nt = (t0 + i) % NTW;
+                    const unsigned voff =
+                        ovoff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        old[i][g4] = __builtin_amdgcn_raw_buffer_load_b128(
+                            orsrc, voff + g4 * 32, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (t0 + i >= MTW * NTW) break;
+                const int mt = (t0 + i) / NTW, nt = (t0 + i) % NTW;
+                const unsigned voff =
+                    ovoff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    pm_u4 r;
+                    r.x = __float_as_uint(__uint_as_float(old[i][g4].x) +
+                                          trunk[mt][nt][4 * g4 + 0] * sc);
+                    r.y = __float_as_uint(__uint_as_float(old[i][g4].y) +
+                                          trunk[mt][nt][4 * g4 + 1] * sc);
+                    r.z = __float_as_uint(__uint_as_float(old[i][g4].z) +
+                                          trunk[mt][nt][4 * g4 + 2] * sc);
+                    r.w = __float_as_uint(__uint_as_float(old[i][g4].w) +
+                                          trunk[mt][nt][4 * g4 + 3] * sc);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        r, orsrc, voff + g4 * 32, 0, 0);
+                }
+            }
+        }
+        PM_SKEW_MARK(8);
+#ifdef PM_TUNING
+        ph[9] += 1;
+#endif
+    }
+#ifdef PM_TUNING
+    if (a.timeline && threadIdx.x == 0)
+        for (int i = 0; i < 10; ++i) a.timeline[(size_t)blockIdx.x * 16 + i] = ph[i];
+#endif
 }

@@ -52,7 +52,14 @@ inline int pm_device_cus() {
 // never reach. walk_nseg > 0: take the walked variant wherever it exists, with
 // that many segments per utterance; upsample_groups > 0: that many M groups
 // per column tile. 0 = the production heuristics.
-struct PmForce { int walk_nseg = 0; int upsample_groups = 0; };
+// skew: -1 = never the skewed walk, 0 = where it measured faster, 1 = wherever
+// it fits.
+#ifndef PM_SKEW_DEFAULT
+#define PM_SKEW_DEFAULT 0    // (A/B builds: -DPM_SKEW_DEFAULT=-1)
+#endif
+struct PmForce { int walk_nseg = 0; int upsample_groups = 0; int skew = PM_SKEW_DEFAULT; };
+// scratch the skewed walk takes per workgroup, at most
+#define PM_SKEW_WG_SCRATCH (256 << 10)
 inline PmForce& pm_force() { static PmForce f; return f; }
 
 // Latency (narrow-tile) variants can be switched off for A/B runs in a
@@ -238,9 +245,13 @@ template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 2, NTW = 4 
 // halo on both sides of a 256-column tile made it 28 % slower than three pair
 // launches - walked it is 10.6 % faster, profiles/r02/ab_block128_k7_walk.txt)
 template <> struct Block3Cfg<ElemF16, 128, 7>  { enum { WM = 4, WN = 2, NTW = 4 }; };
+// C = 128, k 11: skewed walk only (conv_block3_skew_kernel)
+template <> struct Block3Cfg<ElemF16, 128, 11> { enum { WM = 4, WN = 2, NTW = 4 }; };
 // C = 256, k 3: walked only, 128-column tiles (12 of them halo): 0.67 -> 0.53 ms
 // against three pair launches (profiles/r02/ab_block256_walk.txt)
 template <> struct Block3Cfg<ElemF16, 256, 3>  { enum { WM = 8, WN = 1, NTW = 4 }; };
+// C = 256, k 7: skewed walk only
+template <> struct Block3Cfg<ElemF16, 256, 7>  { enum { WM = 8, WN = 1, NTW = 4 }; };
 // (k 7 the same way: 36 of 128 columns halo, 1.45 vs 1.19 ms - stays on the pair kernel)
 // (k 11 the same way - it fits 160 KB once `t` loses its right margin too - is
 // 7 % slower than three pair launches: 31 % more MFMA work)
@@ -274,9 +285,47 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
     if (a.TL < 32) return hipErrorNotSupported;
     a.ntiles = (a.L + a.TL - 1) / a.TL;
     constexpr int smem = block3_smem_bytes<ET, C, K, WM, WN, NTW>();
+    // Skewed walk (no recompute at all) for grids that fill the chip several
+    // times over: needs scratch, dilations <= 5 and H2 (d + 1) <= 30
+    if constexpr (ET::ESZ == 2 && WM * WN == 8 && NTW >= 2) {
+        typedef SkewGeom<ET, C, K, WM, WN, NTW> GE;
+        static_assert(GE::SCRATCH <= PM_SKEW_WG_SCRATCH, "scratch bound");
+        const int cus = pm_device_cus();
+        const int forced = pm_force().walk_nseg;
+        // Measured at batch 32 x 10 s (profiles/r03/ab_skew.txt): -12 % at C = 128
+        // k 11 (against three pair launches), -7 % at C = 128 k 7, -3.5 % at
+        // C = 64 k 11 (against the walked kernels); where the walked halo is
+        // small (k 3, C = 64 k 7) or the tile narrow (C = 256) its exchange
+        // and carry traffic cost 1 ... 4 % more than the recompute it saves.
+        constexpr bool WINS = (C == 128 && K >= 7) || (C == 64 && K == 11);
+        bool fits = GE::SMEM <= 160 * 1024 && a.niter >= 1 && a.niter <= 3 &&
+                    a.scratch && (cus > 0 || forced) &&
+                    (pm_force().skew > 0 || (pm_force().skew == 0 && WINS));
+        for (int i = 0; i < a.niter; ++i)
+            fits = fits && a.dil[i] >= 1 && a.dil[i] <= 5 &&
+                   ((K - 1) / 2) * (a.dil[i] + 1) <= 30;
+        if (fits) {
+            int nseg = forced ? forced : cus / a.B;
+            if (nseg < 1) nseg = 1;
+            const size_t need = (size_t)a.B * nseg * GE::SCRATCH;
+            if ((forced || (a.L / NC) / nseg >= 4) && need <= a.scratch_bytes) {
+                Block3SkewArgs p;
+                p.a = a; p.nseg = nseg; p.wg_scratch = GE::SCRATCH;
+                p.scratch = a.scratch;
+                auto skew = conv_block3_skew_kernel<ET, C, K, WM, WN, NTW>;
+                hipError_t e = pm_ensure_dynamic_lds(
+                    reinterpret_cast<const void*>(skew), GE::SMEM);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(skew, dim3(a.B * nseg), dim3(WM * WN * 64),
+                                   GE::SMEM, stream, p);
+                return hipGetLastError();
+            }
+        }
+    }
     // Walked variant (no left-halo recompute) for grids that fill the chip
     // several times over, where its carry area (halo rows) fits the LDS
-    if constexpr (ET::ESZ == 2 && WM * WN == 8) {
+    if constexpr (ET::ESZ == 2 && WM * WN == 8 && !(C == 128 && K == 11) &&
+                  !(C == 256 && K == 7)) {
         const int smem_walk = block3_walk_smem_bytes<ET, C, K, WM, WN, NTW>() +
                               block3_carry_bytes<ET, C>(a.halo);
         const int cus = pm_device_cus();
@@ -297,7 +346,7 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
             }
         }
     }
-    if constexpr ((C == 128 && K == 7) || C == 256)
+    if constexpr ((C == 128 && K >= 7) || C == 256)
         return hipErrorNotSupported;  // walked only
     auto kern = conv_block3_kernel<ET, C, K, WM, WN, NTW>;
     hipError_t e = pm_ensure_dynamic_lds(
@@ -318,7 +367,8 @@ static hipError_t launch_block3_ck(const Block3Args& a, hipStream_t stream) {
         for (int i = 0; i < a.niter; ++i) halo += (a.dil[i] + 1) * ((K - 1) / 2);
         const int TL = W::WN * W::NTW * 32 - 2 * halo;
         const int TLn = N::WN * N::NTW * 32 - 2 * halo;
-        const bool allowed = pm_narrow_allowed();
+        // (a forced walk - tests - keeps the 8-wave geometry the walks exist for)
+        const bool allowed = pm_narrow_allowed() && !pm_force().walk_nseg;
         if (allowed && TL > 0 && TLn >= 32 &&
             (long long)((a.L + TL - 1) / TL) * a.B < PM_NARROW_BELOW)
             return launch_block3_cfg<ET, C, K, N>(a, stream);
@@ -427,7 +477,7 @@ static hipError_t launch_mrf_c(const Block3Args (&blocks)[3], hipStream_t stream
         for (int i = 0; i < blocks[2].niter; ++i) halo += (blocks[2].dil[i] + 1) * 5;
         const int TL = W::WN * W::NTW * 32 - 2 * halo;
         const int TLn = N::WN * N::NTW * 32 - 2 * halo;
-        const bool allowed = pm_narrow_allowed();
+        const bool allowed = pm_narrow_allowed() && !pm_force().walk_nseg;
         if (allowed && TL > 0 && TLn >= 32 &&
             (long long)((blocks[0].L + TL - 1) / TL) * blocks[0].B < PM_NARROW_BELOW)
             return launch_mrf_cfg<ET, C, N>(blocks, stream);

@@ -52,7 +52,12 @@ def test_engine_create_validates_configuration():
     assert library.pm_hifigan_features_cl_channels(handle) == 128
     size = library.pm_hifigan_workspace_bytes(handle, 32, 861)
     # 4 rotating fp32 activation buffers of 32 x 861 x 8192 floats + features
-    assert 4 * 32 * 861 * 8192 * 4 <= size < 4 * 32 * 861 * 8192 * 4 + 2 ** 25
+    # + the scratch of the skewed whole-Block walk (256 KiB per workgroup,
+    # max(batch, CUs) workgroups: 64 MiB)
+    buffers = 4 * 32 * 861 * 8192 * 4
+    assert buffers + 2 ** 26 <= size < buffers + 2 ** 26 + 2 ** 25
+    assert library.pm_walk_scratch_bytes(32) == 2 ** 26
+    assert library.pm_walk_scratch_bytes(0) == 0
     # forward before finalize / with null pointers is refused, not a crash
     assert library.pm_hifigan_forward(
         handle, None, None, 1, None, 1, 8, None, 0, None) == -1

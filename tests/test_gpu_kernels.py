@@ -258,6 +258,73 @@ def test_walked_whole_block(device, dtype, channels, kernel_size):
         _lib.check(_lib.lib().pm_debug_force(0, 0))
 
 
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+@pytest.mark.parametrize(
+    'channels,kernel_size',
+    [(64, 3), (64, 7), (64, 11), (128, 3), (128, 7), (128, 11), (256, 3),
+     (256, 7)])
+def test_skewed_whole_block(device, dtype, channels, kernel_size):
+    """The SKEWED walk of a whole Block (conv_block3_skew_kernel: iteration i
+    works 32 i columns behind iteration 0, the trunk moves one tile to the
+    right in the register file between iterations - across waves and steps
+    through scratch - and nothing is computed twice) against the oracle and,
+    where another tiling of the same Block exists, bit for bit against it.
+    Taken when the caller hands scratch over behind the workspace; forced here
+    with 1, 2 and 3 segments per utterance: uneven segments, a segment shorter
+    than a step, an utterance shorter than the skew, every store mode."""
+    _lib = lib()
+    gen = torch.Generator().manual_seed(2000 + channels + kernel_size)
+    dilations = (1, 3, 5)
+    state, tensors = block_fixture(channels, kernel_size, gen, device)
+
+    def pointers(name):
+        return (ctypes.c_void_p * 3)(*[t.data_ptr() for t in tensors[name]])
+
+    dil = (ctypes.c_int * 3)(*dilations)
+    weights = 3 * _lib.lib().pm_op_workspace_bytes(
+        channels, channels, kernel_size)
+    scratch = _lib.lib().pm_walk_scratch_bytes(2)
+    assert scratch > 0
+    ws = torch.empty(weights + scratch, dtype=torch.uint8, device=device)
+    columns = {64: 256 if kernel_size == 3 else 512, 128: 256, 256: 128}[channels]
+
+    def run(x_cl, out, length, mode, size):
+        _lib.check(_lib.lib().pm_block_cl(
+            _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out),
+            pointers('w1'), pointers('b1'), pointers('w2'), pointers('b2'),
+            dil, 3, 2, length, channels, kernel_size, mode, 1 / 3,
+            ws.data_ptr(), size, _lib.stream()))
+        torch.cuda.synchronize()
+
+    try:
+        for nseg, length, mode in (
+                (2, 9 * columns + 37, 0), (3, 13 * columns - 5, 2),
+                (1, 3 * columns, 1), (2, 61, 1), (3, 2 * columns + 1, 2)):
+            _lib.check(_lib.lib().pm_debug_force(nseg, 0))
+            _lib.check(_lib.lib().pm_debug_skew(1))
+            x = torch.randn(2, channels, length, generator=gen)
+            prev = torch.randn(2, channels, length, generator=gen)
+            want = oracle.block(x, state, 'p', kernel_size, dilations)
+            want = {0: want, 1: want / 3, 2: prev + want / 3}[mode]
+            x_cl = to_cl(x).to(device)
+            out = to_cl(prev).to(device)
+            ws[weights:].fill_(0xff)    # (NaN patterns: nothing stale is read)
+            run(x_cl, out, length, mode, ws.numel())
+            error = rel_err(from_cl(out, channels), want)
+            print(f'skewed block C {channels} k {kernel_size} {dtype} nseg '
+                  f'{nseg} L {length}: rel {error:.3e}')
+            assert error < 3 * TOL[dtype], (nseg, length, mode)
+            if (channels, kernel_size) not in ((128, 11), (256, 7)):
+                # the walked / stand-alone tiling of the same Block (no scratch
+                # handed over): same arithmetic per column
+                other = to_cl(prev).to(device)
+                run(x_cl, other, length, mode, weights)
+                assert torch.equal(other, out), (nseg, length)
+    finally:
+        _lib.check(_lib.lib().pm_debug_force(0, 0))
+        _lib.check(_lib.lib().pm_debug_skew(0))
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
 @pytest.mark.parametrize(
     'c_in,c_out,rate',
