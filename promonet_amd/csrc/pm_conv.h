@@ -1715,7 +1715,7 @@ struct SkewGeom {
     static constexpr int NW = WM * WN;
     static constexpr int TB = MTW * 4096;        // a wave's boundary tiles, fp32
     static constexpr int CA = 32 + 4 * H2;       // rows of an `a` carry, at most
-    static constexpr int OFF_AC = 2 * 2 * NW * TB;   // [parity][iteration][wave]
+    static constexpr int OFF_AC = 2 * 2 * WM * TB;   // wrap slots [parity][iteration][wm]
     static constexpr int OFF_TC = OFF_AC + 3 * CA * S;
     static constexpr int SCRATCH = (OFF_TC + 3 * 2 * H2 * S + 255) & ~255;
     static constexpr int SMEM = (RA + RT) * S;
@@ -1742,6 +1742,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
     constexpr int W_MT_STRIDE = W_BIAS + 64;
     constexpr int AUX = 16;        // sc1: served by the L2, never by this CU's L1
     static_assert(NTW >= 2, "the trunk shift needs two tiles per wave");
+    static_assert(ET::ESZ == 2, "the exchange slot is a wave's 64 B x 64 rows of t");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* abuf = smem;
@@ -1939,6 +1940,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
             if (d0 > 1)
                 rows_in(tid, abuf + (AL + H2 - H2 * d0) * S, cin, H2 * (d0 - 1));
         }
+        // (once per step: what the previous step stored into scratch - the
+        // wrap slots are read by ANOTHER wave - has left this wave before the
+        // barriers those reads sit behind)
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         pm_block_sync();
         PM_SKEW_MARK(0);
 
@@ -2042,22 +2047,42 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
             // `t` is stable until the next epilogue 1
             rows_out(te, tbuf + NC * S, 2 * H2, GE::OFF_TC + it * 2 * H2 * S);
             if (more) {
-                // the wave's last tile leaves for its right-hand neighbour
-                const unsigned xo =
-                    (unsigned)(((par * 2 + it) * GE::NW + wave) * GE::TB) +
-                    lane_slot;
+                // The wave's last tile leaves for its right-hand neighbour:
+                // through the part of `t` the NEIGHBOUR's epilogue 1 will
+                // overwrite (64 rows x its own 32 MTW channels = the tile's
+                // 4 KB; nobody else writes there, and the neighbour reads it
+                // before it does) once every wave is done with conv2. The
+                // workgroup's last column wave hands its tile to the FIRST one
+                // of the next step through scratch.
+                pm_block_sync();
+                if (wn + 1 < WN) {
+                    char* slot = tbuf +
+                        (2 * H2 + (wn + 1) * NTW * 32 + (te & 63)) * S +
+                        m_first * ET::ESZ;
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
+                    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const floatx16& v = trunk[mt][NTW - 1];
-                        const pm_u4 u = {__float_as_uint(v[4 * g4 + 0]),
-                                         __float_as_uint(v[4 * g4 + 1]),
-                                         __float_as_uint(v[4 * g4 + 2]),
-                                         __float_as_uint(v[4 * g4 + 3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                            u, srsrc, xo + mt * 4096 + g4 * 1024, 0, 0);
-                    }
+                        for (int g4 = 0; g4 < 4; ++g4)
+                            *reinterpret_cast<float4*>(
+                                slot + mt * 32 * ET::ESZ + g4 * 16) =
+                                acc_quad(trunk[mt][NTW - 1], g4);
+                } else {
+                    const unsigned xo =
+                        (unsigned)(((par * 2 + it) * WM + wm) * GE::TB) +
+                        lane_slot;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const floatx16& v = trunk[mt][NTW - 1];
+                            const pm_u4 u = {__float_as_uint(v[4 * g4 + 0]),
+                                             __float_as_uint(v[4 * g4 + 1]),
+                                             __float_as_uint(v[4 * g4 + 2]),
+                                             __float_as_uint(v[4 * g4 + 3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                u, srsrc, xo + mt * 4096 + g4 * 1024, 0, 0);
+                        }
+                }
                 const int dn = karg->a.dil[it + 1];
                 // a_{it+1} = lrelu(trunk) on [o, o + NC): rows AL + 32 ... of
                 // the next iteration's frame
@@ -2078,29 +2103,43 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
                         trunk[mt][nt] = trunk[mt][nt - 1];
                 rows_in(te, abuf + (AL + H2 - H2 * dn) * S, pre,
                         32 + H2 * (dn - 1));
-                // the slots and carries written above are read by other waves
-                // behind this barrier
                 PM_SKEW_MARK(5);
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-                PM_SKEW_MARK(6);
                 pm_block_sync();
                 PM_SKEW_MARK(7);
-                const unsigned xi = wn > 0
-                    ? (unsigned)(((par * 2 + it) * GE::NW + wave - 1) * GE::TB)
-                    : (unsigned)((((par ^ 1) * 2 + it) * GE::NW + wave + WN - 1) *
-                                 GE::TB) + dead;
+                if (wn > 0) {
+                    const char* slot = tbuf +
+                        (2 * H2 + wn * NTW * 32 + (te & 63)) * S +
+                        m_first * ET::ESZ;
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
+                    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const pm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                            srsrc, xi + lane_slot + mt * 4096 + g4 * 1024, 0,
-                            AUX);
-                        trunk[mt][0][4 * g4 + 0] = __uint_as_float(v.x);
-                        trunk[mt][0][4 * g4 + 1] = __uint_as_float(v.y);
-                        trunk[mt][0][4 * g4 + 2] = __uint_as_float(v.z);
-                        trunk[mt][0][4 * g4 + 3] = __uint_as_float(v.w);
-                    }
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const float4 v = *reinterpret_cast<const float4*>(
+                                slot + mt * 32 * ET::ESZ + g4 * 16);
+                            trunk[mt][0][4 * g4 + 0] = v.x;
+                            trunk[mt][0][4 * g4 + 1] = v.y;
+                            trunk[mt][0][4 * g4 + 2] = v.z;
+                            trunk[mt][0][4 * g4 + 3] = v.w;
+                        }
+                } else {
+                    // (written one step ago, many barriers and drained loads
+                    // back; `dead`: zeros on a segment's first step)
+                    const unsigned xi =
+                        (unsigned)((((par ^ 1) * 2 + it) * WM + wm) * GE::TB) +
+                        dead;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const pm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                srsrc, xi + lane_slot + mt * 4096 + g4 * 1024, 0,
+                                AUX);
+                            trunk[mt][0][4 * g4 + 0] = __uint_as_float(v.x);
+                            trunk[mt][0][4 * g4 + 1] = __uint_as_float(v.y);
+                            trunk[mt][0][4 * g4 + 2] = __uint_as_float(v.z);
+                            trunk[mt][0][4 * g4 + 3] = __uint_as_float(v.w);
+                        }
+                }
             }
         }
 

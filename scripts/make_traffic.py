@@ -13,7 +13,7 @@ def label(kernel):
     m = re.match(r'conv_pair_kernel<\w+,(\d+),(\d+),', kernel)
     if m:
         return f'pair_c{m.group(1)}_k{m.group(2)}'
-    m = re.match(r'conv_block3(?:_walk)?_kernel<\w+,(\d+),(\d+),', kernel)
+    m = re.match(r'conv_block3(?:_walk|_skew)?_kernel<\w+,(\d+),(\d+),', kernel)
     if m:
         return f'block_c{m.group(1)}_k{m.group(2)}'
     m = re.match(r'conv_mrf(?:_walk)?_kernel<\w+,(\d+),', kernel)

@@ -35,6 +35,7 @@ for channels, length, k in ((128, 55104, 11), (128, 55104, 7), (128, 55104, 3),
             batch, length, channels, k, 2, 1. / 3, ws.data_ptr(), ws.numel(),
             _lib.stream()))
 
+    _lib.check(lib.pm_debug_skew(1))       # every shape on the skewed kernel
     run()
     torch.cuda.synchronize()
     lib.pm_debug_timeline(stamps.data_ptr())
@@ -44,6 +45,7 @@ for channels, length, k in ((128, 55104, 11), (128, 55104, 7), (128, 55104, 3),
     end.record()
     torch.cuda.synchronize()
     lib.pm_debug_timeline(None)
+    _lib.check(lib.pm_debug_skew(0))
     t = stamps.cpu().double()
     t = t[t[:, 9] > 0]
     steps = t[:, 9].mean().item()
