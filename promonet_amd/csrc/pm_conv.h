@@ -2157,15 +2157,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
             max(own_n, 0) * C * 4, 0x00020000);
         const unsigned ovoff0 = (unsigned)(
             ((o - own_first + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
-        // (MRF accumulation: the reads of `out` go out two tiles at a time
-        // before the first store of the pair - one round trip per pair)
+        // (MRF accumulation: the reads of `out` of up to four tiles go out
+        // before the first store - the operand pipeline's registers are free
+        // here -, one HBM round trip per step instead of one per tile)
         const float sc = mode == 0 ? 1.f : scale;
+        constexpr int NB = MTW * NTW < 4 ? MTW * NTW : 4;
 #pragma unroll
-        for (int t0 = 0; t0 < MTW * NTW; t0 += 2) {
-            pm_u4 old[2][4] = {};
+        for (int t0 = 0; t0 < MTW * NTW; t0 += NB) {
+            pm_u4 old[NB][4] = {};
             if (mode == 2) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NB; ++i) {
                     if (t0 + i >= MTW * NTW) break;
                     const int mt = (t0 + i) / NTW, nt = (t0 + i) % NTW;
                     const unsigned voff =
@@ -2177,7 +2179,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NB; ++i) {
                 if (t0 + i >= MTW * NTW) break;
                 const int mt = (t0 + i) / NTW, nt = (t0 + i) % NTW;
                 const unsigned voff =

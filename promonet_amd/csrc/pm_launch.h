@@ -292,12 +292,13 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
         static_assert(GE::SCRATCH <= PM_SKEW_WG_SCRATCH, "scratch bound");
         const int cus = pm_device_cus();
         const int forced = pm_force().walk_nseg;
-        // Measured at batch 32 x 10 s (profiles/r03/ab_skew.txt): -12 % at C = 128
-        // k 11 (against three pair launches), -7 % at C = 128 k 7, -3.5 % at
-        // C = 64 k 11 (against the walked kernels); where the walked halo is
-        // small (k 3, C = 64 k 7) or the tile narrow (C = 256) its exchange
-        // and carry traffic cost 1 ... 4 % more than the recompute it saves.
-        constexpr bool WINS = (C == 128 && K >= 7) || (C == 64 && K == 11);
+        // Measured at batch 32 x 10 s (profiles/r03/ab_skew.txt): -14 % at C = 128
+        // k 11 (against three pair launches), -10 % at C = 128 k 7, -7 % at
+        // C = 64 k 11, -1.3 % at C = 64 k 7 (against the walked kernels); where
+        // the walked halo is small (k 3: 12 columns) its carries and the
+        // hand-over cost 5 % more than the recompute they save, on the
+        // 128-column tiles of C = 256 k 7 it is even with three pair launches.
+        constexpr bool WINS = (C == 128 || C == 64) && K >= 7;
         bool fits = GE::SMEM <= 160 * 1024 && a.niter >= 1 && a.niter <= 3 &&
                     a.scratch && (cus > 0 || forced) &&
                     (pm_force().skew > 0 || (pm_force().skew == 0 && WINS));
