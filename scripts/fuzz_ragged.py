@@ -2,9 +2,12 @@
 forward must equal the stand-alone synthesis of every utterance bit for bit
 (wide and narrow tile variants, every utterance-edge / tile-edge alignment the
 buffer-descriptor addressing has to get right), tails must be zero.
-usage: python scripts/fuzz_ragged.py [trials] [seed] [max batch]
+usage: python scripts/fuzz_ragged.py [trials] [seed] [max batch] [force]
 (batches of 20+ utterances of 100+ frames run the wide tile variants; max
-batch <= 4 switches to long utterances, which run the walked kernels)"""
+batch <= 4 switches to long utterances, which run the walked kernels; `force`
+= 1: the batched run is forced onto the walked / skewed kernels with 1 ... 5
+segments per utterance (pm_debug_force / pm_debug_skew), the stand-alone runs
+onto the plain tilings)"""
 import random
 import sys
 from pathlib import Path
@@ -20,6 +23,8 @@ import promonet_amd  # noqa: E402
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 max_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+force = len(sys.argv) > 4 and sys.argv[4] == '1'
+from promonet_amd import _lib  # noqa: E402
 device = torch.device('cuda:0')
 state = oracle.random_state(seed=0)
 models = {}
@@ -46,7 +51,14 @@ for trial in range(trials):
         for tensor in inputs[:4]:
             tensor[item, ..., length:] = 7.          # garbage past the end
     with torch.inference_mode():
+        if force:
+            nseg = rng.randint(1, 5)
+            _lib.check(_lib.lib().pm_debug_force(nseg, 0))
+            _lib.check(_lib.lib().pm_debug_skew(rng.choice((0, 1))))
         ragged = model(*inputs, None, lengths=lengths)
+        if force:
+            _lib.check(_lib.lib().pm_debug_force(0, 0))
+            _lib.check(_lib.lib().pm_debug_skew(-1))
         for item, length in enumerate(lengths):
             single = model(
                 *[t[item:item + 1, ..., :length] if t.ndim >= 2
@@ -61,5 +73,7 @@ for trial in range(trials):
                       f'item {item}: same {same} tail-zero {clean} '
                       f'finite {finite}')
     print(f'trial {trial} {dtype} lengths {lengths}: ok', flush=True)
+if force:
+    _lib.check(_lib.lib().pm_debug_skew(0))
 print('fuzz_ragged:', 'FAILED %d' % bad if bad else 'all %d trials exact' % trials)
 sys.exit(1 if bad else 0)
