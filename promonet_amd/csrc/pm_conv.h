@@ -1684,17 +1684,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_walk_kernel(
 // (H2 (d + 1) <= 30). A step advances every window by exactly NC columns.
 //   * the fp32 trunk stays in the accumulator layout; between two iterations
 //     it moves one 32-column tile to the right in the register file (the
-//     window moves 32 columns left): within a wave by register moves, across
-//     waves through a 4 KB slot of L2-resident scratch per wave, written in
-//     epilogue 2 and read back under the next conv1 (the first tile of the
-//     workgroup comes from the slot its last wave wrote one step earlier);
+//     window moves 32 columns left): within a wave by register moves, from
+//     wave to wave through the part of `t` the receiving wave's next
+//     epilogue 1 overwrites anyway (4 KB, one more barrier per iteration);
+//     the workgroup's first tile comes from a slot of scratch its last column
+//     wave wrote one step earlier (slots alternate with the step's parity);
 //   * the left context of a layer's input - the last 32 + H2 (d - 1) columns
 //     of `a`, the last 2 H2 of `t` - is what the previous step left behind;
-//     it travels through scratch as well (the LDS holds the two operand tiles
-//     and nothing else);
+//     it travels through scratch too, each 16 bytes written and read back by
+//     the same thread (the LDS holds the two operand tiles and nothing else:
+//     C = 128 k 11 fits in 156 128 bytes);
 //   * conv1 of iteration 0 needs lrelu(x) H2 (d_0 + 1) columns beyond the
-//     trunk's window: a 32-column strip is staged next to it.
-// Same arithmetic per column as every other tiling of the Block.
+//     trunk's window: a 32-column strip is staged next to it;
+//   * everything a step needs from memory is requested under the MFMA loop in
+//     front of it: x and the strip of the next step under the last conv2
+//     (into the dead conv1 accumulators), an iteration's `a` carry under the
+//     previous conv2, its `t` carry under its conv1.
+// A segment's first step starts halo columns early (or one tile early at the
+// utterance start) and stores nothing it cannot vouch for; its last step runs
+// 32 (niter - 1) columns past the segment. Same arithmetic per column as
+// every other tiling of the Block (tests: bit-identical).
 // ---------------------------------------------------------------------------
 struct Block3SkewArgs {
     Block3Args a;
@@ -1834,8 +1843,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
 
 #ifdef PM_TUNING
     // phase totals of wave 0 (shader clocks): 0 stage, 1 conv1, 2 epilogue 1,
-    // 3 its barrier, 4 conv2, 5 epilogue 2, 6 store drain, 7 its barrier,
-    // 8 output store, 9 steps
+    // 3 its barrier, 4 conv2, 5 epilogue 2 (hand-over included), 6 unused,
+    // 7 its barrier, 8 output store, 9 steps
     unsigned long long ph[10] = {};
     unsigned long long last = __builtin_amdgcn_s_memtime();
 #define PM_SKEW_MARK(k)                                                       \
