@@ -649,7 +649,15 @@ static Plan make_plan(pm_hifigan_t h, int B, int T) {
     p.off_gbias = align256((size_t)B * T * h->cfp * sizeof(float));
     p.off_buf = p.off_gbias + align256((size_t)B * h->c0p * sizeof(float));
     p.off_scratch = p.off_buf + 4 * p.buf_elems * sizeof(float);
-    p.scratch = walk_scratch_bytes(B);
+    // (the skewed walk is only taken with >= 4 steps of >= 256 columns per
+    // segment, max(1, CUs / B) segments per utterance: short calls - a
+    // streaming frame, a single 2 s utterance - carry no scratch)
+    {
+        const int cus = pm_device_cus();
+        const size_t nseg = std::max(1, (cus > 0 ? cus : 256) / B);
+        p.scratch = pm_force().walk_nseg || L / 256 / nseg >= 4
+            ? walk_scratch_bytes(B) : 0;   // (a forced walk: tests)
+    }
     p.total = p.off_scratch + p.scratch;
     return p;
 }
@@ -786,7 +794,8 @@ static int forward_impl(
                 }
                 a.B = B; a.L = L; a.mode = j == 0 ? 1 : 2; a.scale = scale;
                 a.lengths = lengths; a.len_scale = rate;
-                a.scratch = base + p.off_scratch; a.scratch_bytes = p.scratch;
+                a.scratch = p.scratch ? base + p.off_scratch : nullptr;
+                a.scratch_bytes = p.scratch;
                 char label[64];
                 snprintf(label, sizeof(label), "block_c%d_k%d", st.cout, K);
                 hipError_t e = hipSuccess;

@@ -57,6 +57,8 @@ def test_engine_create_validates_configuration():
     buffers = 4 * 32 * 861 * 8192 * 4
     assert buffers + 2 ** 26 <= size < buffers + 2 ** 26 + 2 ** 25
     assert library.pm_walk_scratch_bytes(32) == 2 ** 26
+    # (a single 2 s utterance never takes the skewed walk: no scratch)
+    assert library.pm_hifigan_workspace_bytes(handle, 1, 172) < 2 ** 26
     assert library.pm_walk_scratch_bytes(0) == 0
     # forward before finalize / with null pointers is refused, not a crash
     assert library.pm_hifigan_forward(
