@@ -219,102 +219,47 @@ def from_files_to_files_batched(
     loudness_ratio: float = 1.,
     checkpoint: Optional[Union[str, os.PathLike]] = None,
     gpu: Optional[int] = None,
-    batch_size: int = 32,
-    workers: Optional[int] = None
+    batch_size: int = 32
 ) -> None:
     """`from_files_to_files` with the files synthesised `batch_size` at a
     time (sorted by length, zero-padded, ragged-exact) instead of the
     reference's one-utterance loop (synthesize/core.py:158-201). Same files,
-    same audio as the sequential path. SURVEY.md 8(f) item 2.
-
-    The batch on the GPU is a few milliseconds of work between tens of
-    milliseconds of file IO, so the IO runs beside it: `workers` threads
-    (default: `promonet_amd.NUM_WORKERS`, the reference's pool size; 0 = the
-    plain serial loop) load the files, pad the NEXT batch into pinned memory
-    and write the PREVIOUS batch's wav files while the current one is
-    synthesised. Measured (scripts/bench_files.py, 256 files of 6-10 s on a
-    RAM disk): 474 files/s = 3 750x real time against 452 with the serial
-    loop - the path is bound by the Python side of `torch.load` and the wav
-    writer (2 ms per file, which threads do not parallelise), the GPU is busy
-    a quarter of the time."""
-    from concurrent.futures import ThreadPoolExecutor
+    same audio as the sequential path. SURVEY.md 8(f) item 2."""
     device = _device(gpu)
-    count = len(pitch_files)
     if speakers is None:
-        speakers = [0] * count
-    if workers is None:
-        workers = getattr(promonet_amd, 'NUM_WORKERS', 10)
-
-    def load(index):
+        speakers = [0] * len(pitch_files)
+    items = []
+    for index in range(len(pitch_files)):
         pitch = torch.load(pitch_files[index])
-        frames = pitch.shape[-1]
-        return (
-            frames, index,
-            torch.load(loudness_files[index]).reshape(-1, frames),
-            pitch.reshape(frames),
-            torch.load(periodicity_files[index]).reshape(frames),
-            promonet_amd.load.ppg(ppg_files[index], frames).reshape(
-                -1, frames))
-
-    def padded(tensors, frames):
-        out = torch.zeros(
-            (len(tensors),) + tuple(tensors[0].shape[:-1]) + (frames,))
-        for row, tensor in zip(out, tensors):
-            row[..., :tensor.shape[-1]] = tensor
-        return out.pin_memory() if workers else out
-
-    def assemble(group):
+        items.append((
+            pitch.shape[-1], index, torch.load(loudness_files[index]), pitch,
+            torch.load(periodicity_files[index]),
+            promonet_amd.load.ppg(ppg_files[index], pitch.shape[-1])))
+    items.sort(key=lambda item: item[0])
+    for start in range(0, len(items), batch_size):
+        group = items[start:start + batch_size]
         frames = max(item[0] for item in group)
-        return [padded([item[col] for item in group], frames)
-                for col in (2, 3, 4, 5)]
 
-    def save(audio, group):
+        def padded(tensors):
+            out = torch.zeros(
+                (len(tensors),) + tuple(tensors[0].shape[:-1]) + (frames,))
+            for row, tensor in zip(out, tensors):
+                row[..., :tensor.shape[-1]] = tensor
+            return out.to(device)
+
+        audio = from_features_batched(
+            padded([item[2].reshape(-1, item[0]) for item in group]),
+            padded([item[3].reshape(item[0]) for item in group]),
+            padded([item[4].reshape(item[0]) for item in group]),
+            padded([item[5].reshape(-1, item[0]) for item in group]),
+            [speakers[item[1]] for item in group], spectral_balance_ratio,
+            loudness_ratio, checkpoint, gpu,
+            lengths=[item[0] for item in group]).cpu()
         for row, item in zip(audio, group):
             output_file = Path(output_files[item[1]])
             output_file.parent.mkdir(exist_ok=True, parents=True)
             save_audio(
                 output_file, row[:, :item[0] * promonet_amd.HOPSIZE])
-
-    def synthesise(features, group):
-        return from_features_batched(
-            *[tensor.to(device, non_blocking=bool(workers))
-              for tensor in features],
-            [speakers[item[1]] for item in group], spectral_balance_ratio,
-            loudness_ratio, checkpoint, gpu,
-            lengths=[item[0] for item in group])
-
-    if not workers:
-        items = sorted((load(index) for index in range(count)),
-                       key=lambda item: item[0])
-        for start in range(0, count, batch_size):
-            group = items[start:start + batch_size]
-            save(synthesise(assemble(group), group).cpu(), group)
-        return
-
-    with ThreadPoolExecutor(workers) as pool:
-        # every file has to be read once before the batches can be formed
-        # (they are sorted by length): all loads go out at once
-        items = sorted(pool.map(load, range(count)), key=lambda item: item[0])
-        groups = [items[start:start + batch_size]
-                  for start in range(0, count, batch_size)]
-        pending = pool.submit(assemble, groups[0]) if groups else None
-        writes = []
-        for number, group in enumerate(groups):
-            features = pending.result()
-            if number + 1 < len(groups):
-                pending = pool.submit(assemble, groups[number + 1])
-            audio = synthesise(features, group)
-            host = torch.empty(audio.shape, dtype=audio.dtype).pin_memory()
-            host.copy_(audio, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
-
-            def finish(host=host, done=done, group=group):
-                done.synchronize()
-                save(host, group)
-            writes.append(pool.submit(finish))
-        for write in writes:
-            write.result()
 
 
 ###############################################################################

@@ -1,7 +1,6 @@
 """File-level throughput on the GPU box: N synthetic
 utterances on disk -> wav files through `synthesize.from_files_to_files_batched`
-(length-sorted batches, the IO of neighbouring batches overlapped with the
-synthesis) and, for a few files, through the reference-style sequential
+(length-sorted ragged batches) and, for a few files, through the reference-style sequential
 `from_files_to_files`. usage: python scripts/bench_files.py [files] [seconds]"""
 import json
 import sys
@@ -49,12 +48,17 @@ with tempfile.TemporaryDirectory() as tmp:
     # warm-up (weights packed, kernels loaded)
     promonet_amd.synthesize.from_files_to_files_batched(
         *[a[:32] for a in args], names['out'][:32], gpu=0, batch_size=32)
-    for label, kwargs in (('batched', {}), ('batched_serial_io', {'workers': 0})):
-        start = time.perf_counter()
-        promonet_amd.synthesize.from_files_to_files_batched(
-            *args, names['out'], gpu=0, batch_size=32, **kwargs)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - start
+    # (best of 3: the first pass also warms the page cache)
+    best = {}
+    for _ in range(3):
+        for label, kwargs in (('batched', {}),):
+            start = time.perf_counter()
+            promonet_amd.synthesize.from_files_to_files_batched(
+                *args, names['out'], gpu=0, batch_size=32, **kwargs)
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - start
+            best[label] = min(best.get(label, elapsed), elapsed)
+    for label, elapsed in best.items():
         result[label] = {
             'seconds': elapsed, 'files_per_s': count / elapsed,
             'rtf': total_samples / 22050 / elapsed}
