@@ -11,10 +11,17 @@ endif
 SRC = promonet_amd/csrc
 OBJ = build/obj
 LIB = promonet_amd/lib/libpromonet_hip.so
-OBJS = $(OBJ)/pm_api.o $(OBJ)/pm_conv_f16.o $(OBJ)/pm_conv_bf16.o $(OBJ)/pm_conv_f32.o
+OBJS = $(OBJ)/pm_api.o $(OBJ)/pm_conv_f16.o $(OBJ)/pm_conv_bf16.o $(OBJ)/pm_conv_f32.o \
+       $(OBJ)/pm_conv_f16_mrf.o $(OBJ)/pm_conv_bf16_mrf.o
+# the whole-MRF kernels: see pm_conv_bf16_mrf.hip
+MRF_FLAGS = -mllvm -amdgpu-sched-strategy=max-ilp
 HDRS = $(wildcard $(SRC)/*.h) include/promonet_hip.h
 
 all: $(LIB)
+
+$(OBJ)/%_mrf.o: $(SRC)/%_mrf.hip $(HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(CXXFLAGS) $(MRF_FLAGS) -c $< -o $@
 
 $(OBJ)/%.o: $(SRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJ)

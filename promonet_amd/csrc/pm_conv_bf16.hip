@@ -5,6 +5,5 @@ template hipError_t pm_launch_pair<ElemBF16>(int, int, const PairArgs&, hipStrea
 template int pm_pair_tile_len<ElemBF16>(int, int);
 template hipError_t pm_launch_single<ElemBF16>(int, int, int, const SingleArgs&, hipStream_t);
 template hipError_t pm_launch_block3<ElemBF16>(int, int, const Block3Args&, hipStream_t);
-template hipError_t pm_launch_mrf<ElemBF16>(int, const Block3Args (&)[3], hipStream_t);
 template int pm_pair_chunk<ElemBF16>(int);
 template bool pm_block3_supported<ElemBF16>(int, int);

@@ -256,6 +256,7 @@ def test_no_kernel_spills():
     done = subprocess.run(
         [sys.executable, str(root / 'scripts' / 'check_spills.py')] +
         [str(o) for o in objects if o.name in (
-            'pm_api.o', 'pm_conv_f16.o', 'pm_conv_bf16.o', 'pm_conv_f32.o')],
+            'pm_api.o', 'pm_conv_f16.o', 'pm_conv_bf16.o', 'pm_conv_f32.o',
+            'pm_conv_f16_mrf.o', 'pm_conv_bf16_mrf.o')],
         capture_output=True, text=True)
     assert done.returncode == 0, done.stderr[-2000:]
