@@ -107,97 +107,91 @@ def synthetic_inputs(batch, frames, seed, device):
         loudness, pitch, periodicity, ppg, speakers, ones, ones.clone())]
 
 
-def cpu_baseline(model_name, budget=90.):
+def cpu_baseline(model_name, budget=200.):
     """The CPU oracle (a port of the reference's op sequence in PyTorch fp32)
-    timed on this host's cores: BASELINE.json config 2
-    in full (batch 8 x 430 frames; FARGAN: batch 2) at 8, 32, 64 and
-    cpu_count / 2 torch threads, median of 3 runs after a warm-up, every setting
-    reported; and config 1 (one 2 s `from_features` call) at the fastest
-    setting. A setting gets budget / 4 seconds: one whose 8-frame probe says the
-    full runs cannot fit (a big host's threads oversubscribed on these small
-    convolutions can be 1000x slower than 8 threads) runs the largest sample
-    that fits, or is reported from the probe, so that the default bench stays
-    within a few minutes. A reported baseline, not the target."""
+    timed on this host's cores as SURVEY.md section 8(d) specifies:
+      * config 2 (batch 8 x 430 frames; FARGAN: batch 2): one warm-up run, then
+        the MEDIAN OF 3, at 8 torch threads and at min(32, cpus) - the two
+        settings that have been fastest on every host of the pool (all-core
+        settings only document oversubscription: 64 / 128 threads measured
+        0.6-0.8x of 32 in rounds 2-3);
+      * config 3 (batch 32 x 861 frames = 7 053 312 samples; FARGAN: batch 8)
+        ONCE at the faster setting, in chunks of 8 utterances (the host-memory
+        footprint of config 2);
+      * config 1 (one 2 s `from_features`-sized call), median of 3.
+    About 100-130 s of CPU work on the pool's hosts. On a host so slow that the
+    warm-up run alone says the plan cannot fit `budget` seconds the runs are
+    cut (single run instead of a median, config 3 skipped) and the entry says
+    so. A reported baseline, not the target."""
     sys.path.insert(0, str(ROOT / 'oracle'))
     import restatement as oracle
     if model_name == 'fargan':
-        full_batch, full_frames = 2, 430
+        c2_batch, c2_frames, c3_batch, chunk = 2, 430, 8, 2
         state = oracle.random_state_fargan(seed=0)
         forward = oracle.fargan_generator_forward
         name = 'fargan_generator_forward'
     else:
-        full_batch, full_frames = 8, 430
+        c2_batch, c2_frames, c3_batch, chunk = 8, 430, 32, 8
         state = oracle.random_state(seed=0)
         forward = oracle.generator_forward
         name = 'generator_forward'
+    c3_frames = 861
     hop = promonet_amd.HOPSIZE
-    probe_frames = 8
     cpus = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    settings = sorted({t for t in (8, 32, 64, cpus // 2) if 1 <= t <= cpus}
-                      or {cpus})
-    slot = budget / len(settings)
+    settings = sorted({min(8, cpus), min(32, cpus)})
 
-    def run(batch, frames):
+    def run(batch, frames, chunk_size=None):
         inputs = oracle.synthetic_inputs(batch, frames, seed=1234)
+        chunk_size = chunk_size or batch
         start = time.perf_counter()
-        forward(*inputs, state)
+        for first in range(0, batch, chunk_size):
+            forward(*[t[first:first + chunk_size] for t in inputs], state)
         return time.perf_counter() - start
 
+    c2_samples = c2_batch * c2_frames * hop
+    c3_samples = c3_batch * c3_frames * hop
     by_threads, sample_by_threads = {}, {}
     begin = time.perf_counter()
+    spent = lambda: time.perf_counter() - begin     # noqa: E731
     with torch.inference_mode():
         for threads in settings:
             torch.set_num_threads(threads)
-            warm = run(1, probe_frames)                           # warm-up
-            if warm > slot / 4:
-                by_threads[threads] = probe_frames * hop / warm
-                sample_by_threads[threads] = \
-                    f'1 x {probe_frames} frames, the warm-up run only'
+            warm = run(c2_batch, c2_frames)                       # warm-up
+            # the plan from here: 3 runs now, 4 more at the other setting,
+            # config 3 (8 x config 2): ~15 runs' worth
+            if spent() + 3 * warm > .6 * budget:
+                by_threads[threads] = c2_samples / warm
+                sample_by_threads[threads] = (
+                    f'{c2_batch} x {c2_frames} frames (config 2), the warm-up '
+                    f'run only ({warm:.0f} s: slow host)')
                 continue
-            probe = run(1, probe_frames)
-            rate = probe_frames * hop / probe
-            # config 2 in full where it fits: the probe under-predicts (a
-            # batch of long utterances runs ~4x faster per sample than 8
-            # frames), so a first full run is the real sizing
-            full_samples = full_batch * full_frames * hop
-            remaining = slot - warm - probe
-            if full_samples / (4. * rate) <= remaining:
-                first = run(full_batch, full_frames)
-                remaining -= first
-                if 3 * first <= remaining:
-                    times = [run(full_batch, full_frames) for _ in range(3)]
-                    by_threads[threads] = \
-                        full_samples / statistics.median(times)
-                    sample_by_threads[threads] = (
-                        f'{full_batch} x {full_frames} frames (config 2), '
-                        'median of 3 after a warm-up')
-                else:
-                    by_threads[threads] = full_samples / first
-                    sample_by_threads[threads] = (
-                        f'{full_batch} x {full_frames} frames (config 2), '
-                        'single run')
-                continue
-            # largest (batch, frames) <= config 2's whose 3 runs fit the slot
-            affordable = 2. * rate * remaining / 3.3 / hop        # frames
-            if affordable < 2 * probe_frames:
-                by_threads[threads] = rate
-                sample_by_threads[threads] = \
-                    f'1 x {probe_frames} frames, single run'
-                continue
-            batch = int(min(full_batch, max(1, affordable // full_frames)))
-            frames = int(min(full_frames, affordable // batch))
-            times = [run(batch, frames) for _ in range(3)]
-            by_threads[threads] = batch * frames * hop / statistics.median(times)
-            sample_by_threads[threads] = \
-                f'{batch} x {frames} frames, median of 3'
+            times = [run(c2_batch, c2_frames) for _ in range(3)]
+            by_threads[threads] = c2_samples / statistics.median(times)
+            sample_by_threads[threads] = (
+                f'{c2_batch} x {c2_frames} frames (config 2), median of 3 '
+                'after a warm-up')
         threads = max(by_threads, key=by_threads.get)
-        # config 1: one 2 s utterance through the public call's op sequence
         torch.set_num_threads(threads)
+        # config 1: one 2 s utterance through the public call's op sequence
         short_frames = promonet_amd.convert.seconds_to_frames(2.)
         run(1, short_frames)
         short = statistics.median([run(1, short_frames) for _ in range(3)])
-    spent = time.perf_counter() - begin
+        # config 3 itself, once
+        predicted = c3_samples / by_threads[threads]
+        if spent() + predicted <= 1.25 * budget:
+            seconds = run(c3_batch, c3_frames, chunk)
+            config3 = {
+                'seconds': seconds, 'threads': threads,
+                'samples_per_s': c3_samples / seconds,
+                'rtf': c3_samples / seconds / promonet_amd.SAMPLE_RATE,
+                'sample': f'{c3_batch} x {c3_frames} frames, one run in '
+                          f'chunks of {chunk} utterances'}
+        else:
+            config3 = {
+                'skipped': f'predicted {predicted:.0f} s does not fit the '
+                           f'{budget:.0f} s budget on this host'}
+    total = spent()
     torch.set_num_threads(default_threads)
     return {
         'value': by_threads[threads], 'unit': 'samples/s', 'cores': threads,
@@ -208,15 +202,49 @@ def cpu_baseline(model_name, budget=90.):
         'config1_2s_utterance': {
             'seconds': short, 'threads': threads,
             'samples_per_s': short_frames * hop / short,
-            'rtf': short_frames * hop / short / promonet_amd.SAMPLE_RATE},
+            'rtf': short_frames * hop / short / promonet_amd.SAMPLE_RATE,
+            'sample': f'1 x {short_frames} frames, median of 3 after a warm-up'},
+        'config3': config3,
         'host_cpus': cpus,
         'sample': f'oracle/restatement.py {name} (PyTorch CPU port of the '
-                  f'reference op sequence), fp32, at {sorted(by_threads)} torch '
-                  f'threads on {cpus} cpus: config 2 ({full_batch} x '
-                  f'{full_frames} frames) where it fits {slot:.0f} s per '
-                  f'setting ({sample_by_threads}), config 1 (1 x '
-                  f'{short_frames} frames) at {threads} threads; {spent:.0f} s '
-                  f'of CPU work; value = the fastest setting'}
+                  f'reference op sequence), fp32: config 2 ({c2_batch} x '
+                  f'{c2_frames} frames) as warm-up + median of 3 at '
+                  f'{sorted(by_threads)} torch threads of {cpus} cpus, config 1 '
+                  f'(1 x {short_frames} frames) and config 3 ({c3_batch} x '
+                  f'{c3_frames} frames, once) at the faster setting ({threads}); '
+                  f'{total:.0f} s of CPU work; value = config 2 at the faster '
+                  'setting'}
+
+
+class Watchdog:
+    """N > 1: a collective that hangs (a rank that died, a fabric fault) must
+    fail the job - rc 3 within `seconds` - instead of stalling the driver. Armed
+    around every phase that contains a collective; torch's own collective
+    timeout (distributed.init(timeout=...)) is the second line."""
+
+    def __init__(self, seconds=120.):
+        self.seconds, self.timer = seconds, None
+
+    def arm(self, what, seconds=None):
+        import threading
+        self.disarm()
+        seconds = seconds or self.seconds
+
+        def fire():
+            sys.stderr.write(
+                f'bench.py: rank {os.environ.get("RANK", "0")}: "{what}" did '
+                f'not finish within {seconds:.0f} s - collective hang? '
+                'aborting\n')
+            sys.stderr.flush()
+            os._exit(3)
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
 
 
 def parse_profile(text):
@@ -237,7 +265,13 @@ def main():
         args.dtype = 'fp32' if args.model == 'fargan' else 'bf16'
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
-    rank, world, device = promonet_amd.distributed.init()
+    watchdog = Watchdog(float(os.environ.get('PROMONET_BENCH_HANG_SECONDS', 120)))
+    if args.gpus > 1:
+        # (ranks reach the rendezvous up to a minute or two apart on a fresh
+        # box - the first `import torch` pages the image in)
+        watchdog.arm('process-group initialisation', 300.)
+    rank, world, device = promonet_amd.distributed.init(
+        timeout=300. if args.gpus > 1 else None)
     if world != args.gpus:
         raise SystemExit(
             f'bench.py: WORLD_SIZE {world} != --gpus {args.gpus}')
@@ -255,6 +289,8 @@ def main():
         promonet_amd.configure(COMPUTE_DTYPE=args.dtype)
     torch.manual_seed(0)
     model = promonet_amd.model.Generator().to(device).eval()
+    if world > 1:
+        watchdog.arm('weight broadcast')
     promonet_amd.distributed.broadcast_model(model)     # RCCL broadcast
     inputs = synthetic_inputs(args.batch, frames, 1234 + rank, device)
     gather = world > 1 and not args.no_gather
@@ -287,7 +323,17 @@ def main():
     library = _lib.lib()
     engine = None
     forward_events = []
+    def guarded(what):
+        if world > 1:
+            watchdog.arm(what)
+
+    if os.environ.get('PROMONET_BENCH_TEST_STALL_RANK') == str(rank) and world > 1:
+        # test hook (tests/test_gpu_distributed.py): this rank never reaches
+        # the collectives - the others' watchdogs must end the job
+        watchdog.disarm()
+        time.sleep(3600)
     with torch.inference_mode():
+        guarded('warm-up steps')
         for _ in range(args.warmup):
             step()
         if not fargan:
@@ -295,6 +341,7 @@ def main():
             library.pm_hifigan_profile_reset(engine)
             library.pm_hifigan_profile_enable(engine, 1)
         fence()
+        guarded('timed region')
         start = time.perf_counter()
         for _ in range(args.steps):
             if fargan:
@@ -320,21 +367,55 @@ def main():
         if args.sustain > 0:
             per_step = max(elapsed / args.steps, 1e-4)
             count = max(args.steps, int(math.ceil(args.sustain / per_step)))
+            count = min(count, int(60. / per_step) + 1)
             fence()
+            guarded('sustained loop')
             begin = time.perf_counter()
             for _ in range(count):
                 step()
             fence()
             sustained = (time.perf_counter() - begin, count)
 
+        # N > 1: what a sub-linear scaling number would be made of - the same
+        # K steps WITHOUT the collective (compute alone, per rank) and the
+        # collective alone (submitted and drained, nothing to hide under)
+        diagnosis = None
+        if world > 1:
+            guarded('compute-only steps')
+            fence()
+            begin = time.perf_counter()
+            for _ in range(args.steps):
+                audio = model(*inputs, None)
+            torch.cuda.synchronize()
+            compute_own = time.perf_counter() - begin
+            fence()
+            gather_alone = 0.
+            if gather:
+                guarded('gather-only steps')
+                begin = time.perf_counter()
+                for _ in range(args.steps):
+                    pipeline.submit(audio)
+                    pipeline.drain()
+                fence()
+                gather_alone = time.perf_counter() - begin
+            diagnosis = (compute_own, gather_alone)
+
     if world > 1:
-        worst = torch.tensor(
-            [elapsed, sustained[0] if sustained else 0.], device=device)
-        worst = worst.cpu() if backend == 'gloo' else worst
-        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-        elapsed = worst[0].item()
+        watchdog.arm('timing reduction')
+        own = torch.tensor(
+            [elapsed, sustained[0] if sustained else 0., diagnosis[0],
+             diagnosis[1]], dtype=torch.float64, device=device)
+        own = own.cpu() if backend == 'gloo' else own
+        every = [torch.empty_like(own) for _ in range(world)]
+        dist.all_gather(every, own)
+        every = torch.stack([t.cpu() for t in every])        # (world, 4)
+        rank_step_ms = (every[:, 0] / args.steps * 1e3).tolist()
+        rank_compute_ms = (every[:, 2] / args.steps * 1e3).tolist()
+        elapsed = every[:, 0].max().item()
         if sustained:
-            sustained = (worst[1].item(), sustained[1])
+            sustained = (every[:, 1].max().item(), sustained[1])
+        compute_ms = every[:, 2].max().item() / args.steps * 1e3
+        gather_ms = every[:, 3].max().item() / args.steps * 1e3
 
     if rank == 0:
         total_samples = world * samples_per_step * args.steps
@@ -369,6 +450,12 @@ def main():
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': dtype,
+            'accuracy': (
+                'fp32 arithmetic' if fargan else
+                f'{args.dtype} operands at the 1e-4 max-abs gate on RANDOM-INIT '
+                'weights (audio peak 0.017: tests/test_gpu_model.py::'
+                'test_full_size_every_sample); at trained-checkpoint scale see '
+                'DESIGN.md section 3 - the library default is f16'),
             'data': 'synthetic',
             'config': {
                 'workload': workload,
@@ -387,6 +474,28 @@ def main():
             'samples_per_sec_per_gpu': per_gpu,
             'rtf_per_gpu': per_gpu / promonet_amd.SAMPLE_RATE,
         }
+        if world > 1:
+            # (the timed region's max-over-ranks step against the same steps
+            # without the collective: what of the gather is NOT hidden)
+            rccl = None
+            try:
+                rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
+            result['multi_gpu'] = {
+                'world_size_reported_by_backend': dist.get_world_size(),
+                'backend': backend,
+                'rccl_version': rccl,
+                'compute_ms_per_step': compute_ms,
+                'gather_alone_ms_per_step': gather_ms,
+                'exposed_gather_ms': elapsed / args.steps * 1e3 - compute_ms,
+                'rank_ms_per_step': rank_step_ms,
+                'rank_ms_per_step_min': min(rank_step_ms),
+                'rank_ms_per_step_max': max(rank_step_ms),
+                'rank_compute_ms_per_step': rank_compute_ms,
+                'gathered_bytes_per_rank_per_step':
+                    world * samples_per_step * 4 if gather else 0,
+                'hang_watchdog_seconds': watchdog.seconds}
         if sustained:
             seconds, count = sustained
             result['sustained_ms_per_step'] = seconds / count * 1e3
@@ -421,7 +530,10 @@ def main():
             floor_us = 13 * 1.1 + 2 * 1.3 + 4 * 2.3
             result['roofline'] = {
                 'kernel': 'pm_fargan_cluster_kernel',
-                'bound': 'hbm', 'level': 'l2 (weights re-streamed per step)',
+                # (not an HBM fraction: `achieved` / `peak` / `frac` are the L2
+                # -> CU weight stream; the recurrence is latency-bound, see
+                # latency_model.frac_of_latency_floor)
+                'bound': 'l2', 'level': 'l2 (weights re-streamed per step)',
                 'achieved': l2_gbs,
                 'peak': 34500., 'unit': 'GB/s',
                 'frac': l2_gbs / 34500.,
@@ -530,8 +642,10 @@ def main():
         print(json.dumps(result))
 
     if world > 1:
+        watchdog.arm('final barrier')
         dist.barrier()
         dist.destroy_process_group()
+    watchdog.disarm()
 
 
 if __name__ == '__main__':

@@ -198,8 +198,12 @@ int pm_block_iteration_cl(int dtype, const float* x_cl, float* out_cl,
                           int mode, float scale, void* workspace,
                           size_t workspace_bytes, void* stream);
 /* A whole Block (hifigan.py:198-210), all `niter` <= 3 dilations fused in
- * one kernel (channels <= 64); w1/b1/w2/b2 are HOST arrays of `niter` device
- * pointers; workspace >= 3 * pm_op_workspace_bytes(c, c, k)               */
+ * one kernel: 16-bit operands for channels <= 64 at every k, 128 at k 3 and -
+ * walked / skewed variants, taken for long inputs or through pm_debug_force -
+ * 128 at k 7 / 11 and 256 at k 3 / 7; fp32 operands for channels <= 64
+ * (PM_EINVAL "no whole-Block kernel" otherwise: use pm_block_iteration_cl);
+ * w1/b1/w2/b2 are HOST arrays of `niter` device pointers;
+ * workspace >= 3 * pm_op_workspace_bytes(c, c, k) [+ pm_walk_scratch_bytes] */
 int pm_block_cl(int dtype, const float* x_cl, float* out_cl,
                 const float* const* w1, const float* const* b1,
                 const float* const* w2, const float* const* b2,
@@ -247,11 +251,13 @@ int pm_debug_timeline(void* dev_buffer);
  * pm_mrf_cl / the engine and the multi-block path of the wide upsampler are
  * chosen from the grid size; walk_nseg > 0 forces the walked variant with
  * that many segments per utterance, upsample_groups > 0 that many M groups
- * per column tile; 0, 0 restores the heuristics. Process-wide.             */
+ * per column tile; 0, 0 restores the heuristics. State per HOST THREAD;
+ * PM_ESTATE unless the process runs with PROMONET_HIP_DEBUG=1.              */
 int pm_debug_force(int walk_nseg, int upsample_groups);
 /* Test hook: -1 keeps every launcher off the skewed whole-Block walk
  * (conv_block3_skew_kernel), 1 takes it wherever it fits, 0 restores the
- * default (the shapes it measured faster on). Process-wide.                 */
+ * default (the shapes it measured faster on). Per host thread, and only
+ * with PROMONET_HIP_DEBUG=1, like pm_debug_force.                           */
 int pm_debug_skew(int mode);
 /* Scratch the skewed whole-Block walk wants BEHIND the 3 x
  * pm_op_workspace_bytes() of pm_block_cl's workspace for `batch` utterances
@@ -360,7 +366,8 @@ int pm_stft_mel(const float* audio, const void* prepared, float* out,
                 int batch, int samples, int mels, int use_threshold,
                 float log_threshold, void* stream);
 /* Tuning knob: frames per FFT workgroup, 16 (default; two workgroups per CU)
- * or 32 (one 8-wave workgroup, 128-byte output rows)                       */
+ * or 32 (one 8-wave workgroup, 128-byte output rows). Per host thread; an API
+ * call reads it once (both passes of pm_loudness use the same value).      */
 int pm_stft_set_frames_per_group(int frames);
 /* spectrogram.linear_to_mel (spectrogram.py:111-133): log(basis @ spec),
  * optional clamp: spec (B, F, T), basis (Mel, F) -> (B, Mel, T)           */

@@ -121,6 +121,7 @@ def lib():
     return _lib
 
 
+PM_OK, PM_EINVAL, PM_ESTATE, PM_EHIP, PM_ENOMEM = 0, -1, -2, -3, -4
 PM_ETIMEOUT = -5
 
 

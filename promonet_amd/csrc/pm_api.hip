@@ -655,8 +655,9 @@ static Plan make_plan(pm_hifigan_t h, int B, int T) {
     {
         const int cus = pm_device_cus();
         const size_t nseg = std::max(1, (cus > 0 ? cus : 256) / B);
-        p.scratch = pm_force().walk_nseg || L / 256 / nseg >= 4
-            ? walk_scratch_bytes(B) : 0;   // (a forced walk: tests)
+        p.scratch = pm_force().walk_nseg || pm_force().skew > 0 ||
+                    L / 256 / nseg >= 4
+            ? walk_scratch_bytes(B) : 0;   // (a forced walk / skew: tests)
     }
     p.total = p.off_scratch + p.scratch;
     return p;
@@ -1272,7 +1273,25 @@ extern "C" int pm_out_conv_tanh(
 // `walk_nseg` segments per utterance) and the number of M groups of the wide
 // upsampler, which the launchers otherwise pick from the grid size - so that
 // unit-sized inputs reach those code paths. 0 restores the heuristics.
+//
+// The hooks are OFF unless the process was started with PROMONET_HIP_DEBUG=1
+// (tests/conftest.py and the scripts under scripts/ set it): a production
+// process cannot have its launch geometry changed under it. Their state is
+// per host thread (pm_launch.h), so a test thread's override never reaches a
+// forward running on another thread, and every API call reads it on the
+// thread that launches.
+static bool debug_hooks_enabled() {
+    static const bool enabled = [] {
+        const char* e = getenv("PROMONET_HIP_DEBUG");
+        return e && e[0] == '1';
+    }();
+    return enabled;
+}
+
 extern "C" int pm_debug_force(int walk_nseg, int upsample_groups) {
+    if (!debug_hooks_enabled())
+        return fail(PM_ESTATE, "debug hooks are disabled "
+                    "(start the process with PROMONET_HIP_DEBUG=1)");
     if (walk_nseg < 0 || upsample_groups < 0)
         return fail(PM_EINVAL, "negative value");
     pm_force().walk_nseg = walk_nseg;
@@ -1284,6 +1303,9 @@ extern "C" int pm_debug_force(int walk_nseg, int upsample_groups) {
 // it wherever it fits, 0 restores the default (the shapes it measured faster
 // on, when scratch was handed over).
 extern "C" int pm_debug_skew(int mode) {
+    if (!debug_hooks_enabled())
+        return fail(PM_ESTATE, "debug hooks are disabled "
+                    "(start the process with PROMONET_HIP_DEBUG=1)");
     if (mode < -1 || mode > 1) return fail(PM_EINVAL, "mode is -1, 0 or 1");
     pm_force().skew = mode;
     return PM_OK;
@@ -1422,7 +1444,9 @@ extern "C" int pm_stft_magnitude_dft(
 
 // ---- FFT path (forward transforms; pm_fft.h) --------------------------------
 static std::map<int, float*> g_fft_tables;   // per device (g_basis_mutex)
-static int g_fft_frames_per_group = 16;
+// (per host thread, like the other test / tuning hooks: a setter on one thread
+// cannot change the launch geometry of a call in flight on another)
+static thread_local int g_fft_frames_per_group = 16;
 
 static int get_fft_tables(const float** out, hipStream_t s) {
     int dev = 0;
@@ -1460,8 +1484,11 @@ extern "C" int pm_stft_set_frames_per_group(int frames) {
     return PM_OK;
 }
 
+// `frames_per_group`: read ONCE per API call by the caller (pm_loudness runs
+// two passes whose per-group maxima must be indexed the same way)
 template <int EPI>
-static int fft_launch(FftArgs& a, hipStream_t s) {
+static int fft_launch(FftArgs& a, hipStream_t s,
+                      int frames_per_group = g_fft_frames_per_group) {
     const int pad = (NFFT - HOP) / 2;
     if (!a.audio) return fail(PM_EINVAL, "null argument");
     if (a.B < 1 || a.N <= pad)
@@ -1471,7 +1498,7 @@ static int fft_launch(FftArgs& a, hipStream_t s) {
     if (a.B > 65535) return fail(PM_EINVAL, "batch too large (max 65535)");
     int rc = get_fft_tables(&a.tables, s);
     if (rc) return rc;
-    if (g_fft_frames_per_group == 32) {
+    if (frames_per_group == 32) {
         auto kern = pm_stft_fft_kernel<EPI, 8, 4>;
         constexpr int smem = pm_fft_smem_bytes<EPI, 8, 4>();
         HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
@@ -1648,7 +1675,8 @@ extern "C" int pm_loudness(
     FftArgs a = {};
     a.audio = audio; a.out = out; a.B = B; a.N = N;
     a.group_max = (float*)scratch;
-    int rc = fft_launch<2>(a, s);
+    const int frames_per_group = g_fft_frames_per_group;   // both passes
+    int rc = fft_launch<2>(a, s, frames_per_group);
     if (rc) return rc;
     a.weights = a_weights; a.rows = bands;
     const double step = (double)BINS / (double)bands;   // loudness.py:96
@@ -1656,7 +1684,7 @@ extern "C" int pm_loudness(
         a.band_start[b] = (int)(b * step);
     if (bands == 1) { a.band_start[0] = 0; a.band_start[1] = BINS; }
     a.min_db = min_db; a.top_db = 80.f;
-    return fft_launch<3>(a, s);
+    return fft_launch<3>(a, s, frames_per_group);
 }
 
 // promonet.edit feature editing (edit/core.py:17-132, edit/grid.py:12-45)

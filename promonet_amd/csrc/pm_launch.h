@@ -60,7 +60,8 @@ inline int pm_device_cus() {
 struct PmForce { int walk_nseg = 0; int upsample_groups = 0; int skew = PM_SKEW_DEFAULT; };
 // scratch the skewed walk takes per workgroup, at most
 #define PM_SKEW_WG_SCRATCH (256 << 10)
-inline PmForce& pm_force() { static PmForce f; return f; }
+// (per host thread: see pm_debug_force in pm_api.hip)
+inline PmForce& pm_force() { static thread_local PmForce f; return f; }
 
 // Latency (narrow-tile) variants can be switched off for A/B runs in a
 // -DPM_TUNING build only; the shipped library reads no environment.

@@ -602,25 +602,40 @@ __global__ __launch_bounds__(256) void pm_stretch_grid_kernel(StretchArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ float sel_lds[];         // T floats when they fit
     __shared__ float red[4];
+    __shared__ int bad_row;
     const int tid = threadIdx.x;
     const bool in_lds = (size_t)a.T * sizeof(float) <= 64 * 1024;
+    if (tid == 0) bad_row = 0;
+    __syncthreads();
     float partial = 0.f;
+    bool bad = false;
     for (int t = tid; t < a.T; t += 256) {
         float s = 0.f;
         for (int k = 0; k < a.n; ++k) {
-            // a row outside the PPG reads nothing and poisons the grid (NaN)
+            // a row outside the PPG reads nothing (and poisons the grid, below)
             const int row = a.indices[k];
-            s += row >= 0 && row < a.P ? a.ppg[(size_t)row * a.T + t]
-                                       : __builtin_nanf("");
+            if (row >= 0 && row < a.P) s += a.ppg[(size_t)row * a.T + t];
+            else bad = true;
         }
         a.selected[t] = s;
         if (in_lds) sel_lds[t] = s;
         partial += s;
     }
+    if (bad) bad_row = 1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = partial;
     __syncthreads();
+    if (bad_row) {
+        // NaN as a BIT PATTERN through integer stores: this translation unit
+        // is built -fno-honor-nans, under which floating-point arithmetic on
+        // a NaN (and __builtin_nanf itself) is undefined to the compiler
+        for (int j = tid; j < a.target; j += 256)
+            reinterpret_cast<unsigned*>(a.grid)[j] = 0x7fc00000u;
+        for (int t = tid; t < a.T; t += 256)
+            reinterpret_cast<unsigned*>(a.selected)[t] = 0x7fc00000u;
+        return;
+    }
     if (tid != 0) return;
     const float* sel = in_lds ? sel_lds : a.selected;
     const float total = red[0] + red[1] + red[2] + red[3];

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None, force=False):
+def init(backend=None, force=False, timeout=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE /
     LOCAL_RANK / MASTER_ADDR / MASTER_PORT). Returns (rank, world, device).
     `force` creates the process group for a single rank too (a 1-GPU box can
@@ -24,7 +24,9 @@ def init(backend=None, force=False):
     One rank per GPU over RCCL ("nccl"). When there are more local ranks than
     GPUs (a 1-GPU test box running the 2-rank path) the ranks fold onto the
     devices round-robin and the backend falls back to gloo - RCCL refuses two
-    ranks on one device - with the collectives staged through host memory."""
+    ranks on one device - with the collectives staged through host memory.
+    `timeout` (seconds; default: torch's 10 / 30 minutes) bounds every
+    collective: a rank that never arrives fails the job instead of hanging it."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -41,7 +43,11 @@ def init(backend=None, force=False):
         folded = use_gpu and local_world > devices
         backend = backend or os.environ.get('PROMONET_DIST_BACKEND') or (
             'nccl' if use_gpu and not folded else 'gloo')
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        extra = {}
+        if timeout is not None:
+            import datetime
+            extra['timeout'] = datetime.timedelta(seconds=float(timeout))
+        dist.init_process_group(backend, rank=rank, world_size=world, **extra)
     return rank, world, device
 
 

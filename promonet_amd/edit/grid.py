@@ -86,11 +86,16 @@ def selective(ppg, ratio, indices):
     # (editing is not the throughput path: one sync buys a loud failure where
     # the reference's arithmetic silently yields inf / NaN / a grid that runs
     # backwards - no probability mass on the selected phonemes, or more
-    # unselected mass than output frames)
+    # unselected mass than output frames. Non-DEcreasing is enough: a step
+    # below one ulp of the position - a very large effective ratio on a long
+    # grid - repeats a value, which the reference returns as well. Deviation
+    # from the reference, deliberate: where its position runs past the last
+    # frame it raises IndexError; the kernel clamps the read and the grid keeps
+    # the formula's values.)
     if target > 1 and not bool(
-            (torch.isfinite(grid).all() & (grid[1:] > grid[:-1]).all())):
+            (torch.isfinite(grid).all() & (grid[1:] >= grid[:-1]).all() &
+             (grid[-1] > grid[0]))):
         raise ValueError(
             'selective grid: the selected phonemes carry too little '
-            'probability mass for this ratio (non-finite or non-increasing '
-            'grid)')
+            'probability mass for this ratio (non-finite or decreasing grid)')
     return grid

@@ -197,10 +197,7 @@ class FARGAN(torch.nn.Module):
                     'FARGAN: check_exchange=False needs an explicit '
                     'kernel_mode (1 or 2)')
 
-            def launch():
-                mode = self.kernel_mode
-                if mode == 0 and self._fallback_calls > 0:
-                    mode = 1
+            def launch(mode):
                 _lib.check(lib.pm_fargan_set_mode(engine, mode))
                 if lengths is None:
                     _lib.check(lib.pm_fargan_forward(
@@ -222,11 +219,14 @@ class FARGAN(torch.nn.Module):
                         engine, batch, frames, self._workspace.data_ptr(),
                         _lib.stream()))
             if self.kernel_mode == 0 and self._fallback_calls > 0:
+                # the mode is chosen BEFORE the counter moves (the call that
+                # takes it to 0 still runs the fallback kernel; the next one
+                # tries the clusters again inside the guarded block below)
+                launch(1)
                 self._fallback_calls -= 1
-                launch()
                 return out
             try:
-                launch()
+                launch(self.kernel_mode)
             except _lib.LibraryError as error:
                 # The cluster kernel needs all its workgroups resident at
                 # once; a GPU shared with another process (or CU-masked) can
@@ -238,7 +238,7 @@ class FARGAN(torch.nn.Module):
                 if self.kernel_mode != 0 or error.code != _lib.PM_ETIMEOUT:
                     raise
                 try:
-                    launch()
+                    launch(0)
                 except _lib.LibraryError as again:
                     if again.code != _lib.PM_ETIMEOUT:
                         raise
@@ -249,7 +249,7 @@ class FARGAN(torch.nn.Module):
                         f'utterance kernel for the next {self.RETRY_AFTER} '
                         'calls')
                     self._fallback_calls = self.RETRY_AFTER
-                    launch()
+                    launch(1)
         return out
 
     def remove_weight_norm(self):

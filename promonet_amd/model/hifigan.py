@@ -38,6 +38,7 @@ class HiFiGAN(torch.nn.Module):
         self._engine = None
         self._engine_key = None
         self._workspace = None
+        self._busy = None        # (stream, event) of the last forward
         self.register_load_state_dict_post_hook(
             lambda module, keys: module._invalidate())
 
@@ -177,6 +178,34 @@ class HiFiGAN(torch.nn.Module):
                 size, dtype=torch.uint8, device=device)
         return self._workspace
 
+    def _claim_workspace(self, device):
+        """One workspace per module: a forward on stream B while the previous
+        one is still running on stream A would overwrite the activations under
+        it. Raise instead (same-stream calls are ordered by the stream; a
+        different stream is fine once the previous forward has finished)."""
+        stream = torch.cuda.current_stream(device)
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if self._busy is not None:
+            previous, event = self._busy
+            if previous != stream and not event.query():
+                raise RuntimeError(
+                    'promonet_amd.model.HiFiGAN: forward on '
+                    f'{stream} while the previous forward is still running on '
+                    f'{previous} - the module owns ONE workspace; wait for it '
+                    '(stream.wait_stream / synchronize) or use one model per '
+                    'stream')
+            event = event if previous.device == stream.device \
+                else torch.cuda.Event()
+        else:
+            event = torch.cuda.Event()
+        return stream, event
+
+    def _release_workspace(self, claim):
+        if claim is not None:
+            claim[1].record(claim[0])
+            self._busy = claim
+
     ###########################################################################
     # Forward
     ###########################################################################
@@ -221,20 +250,24 @@ class HiFiGAN(torch.nn.Module):
             if lengths.shape != (batch,):
                 raise ValueError('lengths must have shape (B,)')
         with torch.cuda.device(x.device):
+            claim = self._claim_workspace(x.device)
             workspace = self.workspace(batch, frames, x.device)
-            if lengths is not None:
-                _lib.check(lib.pm_hifigan_forward_ragged(
-                    engine, _lib.ptr(x), int(channels_last), _lib.ptr(g),
-                    g.shape[0], _lib.ptr(lengths, torch.int32), _lib.ptr(out),
-                    batch, frames, workspace.data_ptr(), workspace.numel(),
-                    _lib.stream()))
-                return out
-            fn = lib.pm_hifigan_forward_cl if channels_last \
-                else lib.pm_hifigan_forward
-            _lib.check(fn(
-                engine, _lib.ptr(x), _lib.ptr(g), g.shape[0], _lib.ptr(out),
-                batch, frames, workspace.data_ptr(), workspace.numel(),
-                _lib.stream()))
+            try:
+                if lengths is not None:
+                    _lib.check(lib.pm_hifigan_forward_ragged(
+                        engine, _lib.ptr(x), int(channels_last), _lib.ptr(g),
+                        g.shape[0], _lib.ptr(lengths, torch.int32),
+                        _lib.ptr(out), batch, frames, workspace.data_ptr(),
+                        workspace.numel(), _lib.stream()))
+                else:
+                    fn = lib.pm_hifigan_forward_cl if channels_last \
+                        else lib.pm_hifigan_forward
+                    _lib.check(fn(
+                        engine, _lib.ptr(x), _lib.ptr(g), g.shape[0],
+                        _lib.ptr(out), batch, frames, workspace.data_ptr(),
+                        workspace.numel(), _lib.stream()))
+            finally:
+                self._release_workspace(claim)
         return out
 
     def remove_weight_norm(self):

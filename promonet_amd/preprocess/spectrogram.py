@@ -73,6 +73,9 @@ def _prepared_mel_basis(device):
             _lib.check(lib.pm_stft_mel_prepare(
                 _lib.ptr(basis), basis.shape[0], prepared.data_ptr(),
                 prepared.numel(), _lib.stream()))
+            # the buffer is cached for every later caller, whatever stream
+            # (or graph capture) it runs on: finish building it first
+            torch.cuda.current_stream(device).synchronize()
         cache[key] = prepared
     return cache[key]
 
@@ -166,10 +169,13 @@ def mel_basis():
     """`librosa.filters.mel(sr=22050, n_fft=1024, n_mels=80)` restated
     (Slaney scale, slaney norm; called at spectrogram.py:118-121).
     PARITY UNPINNED: librosa is absent from the build container."""
-    if not hasattr(mel_basis, 'basis'):
-        sr, n_fft, n_mels = (
-            promonet_amd.SAMPLE_RATE, promonet_amd.NUM_FFT,
-            promonet_amd.NUM_MELS)
+    # (keyed on the configuration: configure(NUM_MELS=...) after a first use
+    # must not pair a stale basis with the new filter count)
+    key = (promonet_amd.SAMPLE_RATE, promonet_amd.NUM_FFT,
+           promonet_amd.NUM_MELS)
+    cache = mel_basis.__dict__.setdefault('cache', {})
+    if key not in cache:
+        sr, n_fft, n_mels = key
 
         def to_mel(f):
             f = np.asarray(f, dtype=np.float64)
@@ -191,8 +197,8 @@ def mel_basis():
         upper = ramps[2:] / widths[1:, None]
         weights = np.maximum(0, np.minimum(lower, upper))
         weights *= (2. / (edges[2:] - edges[:-2]))[:, None]
-        mel_basis.basis = torch.from_numpy(weights.astype(np.float32))
-    return mel_basis.basis
+        cache[key] = torch.from_numpy(weights.astype(np.float32))
+    return cache[key]
 
 
 def linear_to_mel(spectrogram, log_dynamic_range_compression_threshold=None):

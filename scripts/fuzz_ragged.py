@@ -9,7 +9,9 @@ batch <= 4 switches to long utterances, which run the walked kernels; `force`
 segments per utterance (pm_debug_force / pm_debug_skew), the stand-alone runs
 onto the plain tilings)"""
 import random
+import os
 import sys
+os.environ.setdefault('PROMONET_HIP_DEBUG', '1')   # the library's test hooks
 from pathlib import Path
 
 import torch

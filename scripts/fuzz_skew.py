@@ -5,7 +5,9 @@ only the reference's 1 / 3 / 5), iteration counts, lengths, batch sizes and
 store modes. usage: python scripts/fuzz_skew.py [trials] [seed]"""
 import ctypes
 import random
+import os
 import sys
+os.environ.setdefault('PROMONET_HIP_DEBUG', '1')   # the library's test hooks
 from pathlib import Path
 
 import torch

@@ -2,7 +2,9 @@
 box, -DPM_TUNING build): shader clocks of wave 0 per phase, mean over the
 workgroups, per step."""
 import ctypes
+import os
 import sys
+os.environ.setdefault('PROMONET_HIP_DEBUG', '1')   # the library's test hooks
 from pathlib import Path
 
 import torch

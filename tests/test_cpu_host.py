@@ -260,3 +260,47 @@ def test_no_kernel_spills():
             'pm_conv_f16_mrf.o', 'pm_conv_bf16_mrf.o')],
         capture_output=True, text=True)
     assert done.returncode == 0, done.stderr[-2000:]
+
+
+def test_debug_hooks_are_off_in_a_production_process():
+    """pm_debug_force / pm_debug_skew change launch geometry: they answer
+    PM_ESTATE unless the process opted in with PROMONET_HIP_DEBUG=1 (this
+    test session does, tests/conftest.py), and their state is per host
+    thread."""
+    import os
+    import subprocess
+    import sys
+    import threading
+    code = (
+        'from promonet_amd import _lib\n'
+        'lib = _lib.lib()\n'
+        'print(lib.pm_debug_force(2, 0), lib.pm_debug_skew(1), '
+        'lib.pm_last_error().decode())\n')
+    env = {k: v for k, v in os.environ.items() if k != 'PROMONET_HIP_DEBUG'}
+    env['PYTHONPATH'] = str(ROOT)
+    out = subprocess.run(
+        [sys.executable, '-c', code], env=env, capture_output=True, text=True,
+        timeout=300)
+    assert out.returncode == 0, out.stderr
+    first, second, message = out.stdout.strip().split(' ', 2)
+    assert int(first) == int(second) == _lib.PM_ESTATE
+    assert 'PROMONET_HIP_DEBUG' in message
+    # opted in: accepted, and another thread still sees the defaults - its
+    # workspace query (which depends on the forced walk) is unchanged
+    library = _lib.lib()
+    handle = ctypes.c_void_p()
+    assert library.pm_hifigan_create(
+        ctypes.byref(make_config()), ctypes.byref(handle)) == 0
+    plain = library.pm_hifigan_workspace_bytes(handle, 1, 16)
+    assert library.pm_debug_force(2, 0) == 0
+    try:
+        forced = library.pm_hifigan_workspace_bytes(handle, 1, 16)
+        seen = []
+        worker = threading.Thread(target=lambda: seen.append(
+            library.pm_hifigan_workspace_bytes(handle, 1, 16)))
+        worker.start()
+        worker.join()
+        assert forced > plain and seen == [plain]
+    finally:
+        assert library.pm_debug_force(0, 0) == 0
+        library.pm_hifigan_destroy(handle)

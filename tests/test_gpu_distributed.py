@@ -110,6 +110,46 @@ def test_bench_self_launches_two_ranks(device):
     result = json.loads(lines[0])
     assert result['n_gpus'] == 2 and result['world_size'] == 2
     assert result['value'] > 0 and result['scaling'] == 'weak'
+    # the N > 1 line is diagnosable: compute alone, the collective alone, what
+    # of it is exposed, every rank's own step time, the backend's own view
+    multi = result['multi_gpu']
+    assert multi['world_size_reported_by_backend'] == 2
+    assert len(multi['rank_ms_per_step']) == 2
+    assert multi['rank_ms_per_step_min'] <= multi['rank_ms_per_step_max']
+    assert multi['rank_ms_per_step_max'] == pytest.approx(
+        result['ms_per_step'], rel=1e-6)
+    assert multi['compute_ms_per_step'] > 0
+    assert multi['gather_alone_ms_per_step'] > 0
+    assert multi['exposed_gather_ms'] == pytest.approx(
+        result['ms_per_step'] - multi['compute_ms_per_step'], abs=1e-6)
+    assert multi['gathered_bytes_per_rank_per_step'] == 2 * 4 * 172 * 256 * 4
+    assert multi['hang_watchdog_seconds'] == 120
+
+
+def test_bench_fails_fast_on_a_collective_hang(device):
+    """A rank that never reaches a collective must fail the job quickly (rc != 0
+    well inside the driver's patience), not hang it: rank 1 is made to stall
+    in its warm-up (PROMONET_BENCH_TEST_STALL_RANK), rank 0's watchdog -
+    shortened to 20 s here - fires inside the first all-gather."""
+    import subprocess
+    import sys
+    import time
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR',
+                        'MASTER_PORT', 'LOCAL_WORLD_SIZE')}
+    env['PROMONET_BENCH_HANG_SECONDS'] = '20'
+    env['PROMONET_BENCH_TEST_STALL_RANK'] = '1'
+    begin = time.perf_counter()
+    done = subprocess.run(
+        [sys.executable, str(root / 'bench.py'), '--gpus', '2', '--steps', '2',
+         '--warmup', '1', '--batch', '2', '--seconds', '1', '--sustain', '0'],
+        capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert done.returncode != 0
+    assert time.perf_counter() - begin < 240
+    assert 'collective hang' in done.stderr
+    assert not [l for l in done.stdout.splitlines() if l.startswith('{')]
 
 
 ###############################################################################

@@ -124,3 +124,28 @@ def test_selective_grid_rejects_bad_selections(device):
     empty[3] = 0.
     with pytest.raises(ValueError, match='probability mass'):
         promonet_amd.edit.grid.selective(empty, 1.3, [3])
+
+
+def test_stretch_grid_out_of_range_row_is_nan_bits(device):
+    """C ABI below the Python validation: a phoneme row outside the PPG reads
+    nothing and poisons grid and selection with the quiet-NaN BIT PATTERN
+    (written through integer stores - the library is built -fno-honor-nans,
+    so nothing may rest on NaN arithmetic); valid rows are unaffected."""
+    from promonet_amd import _lib
+    gen = torch.Generator().manual_seed(5)
+    ppg = torch.softmax(torch.randn(40, 50, generator=gen), dim=0).to(device)
+    for rows, poisoned in (([1, 40], True), ([-1], True), ([1, 5, 9], False)):
+        index = torch.tensor(rows, dtype=torch.int32, device=device)
+        selected = torch.zeros(50, device=device)
+        grid = torch.zeros(38, device=device)
+        _lib.check(_lib.lib().pm_stretch_grid(
+            _lib.ptr(ppg), 40, _lib.ptr(index, torch.int32), len(rows),
+            _lib.ptr(selected), _lib.ptr(grid), 50, 38, _lib.stream()))
+        torch.cuda.synchronize()
+        bits = grid.view(torch.int32).cpu()
+        if poisoned:
+            assert bool((bits == 0x7fc00000).all())
+            assert bool((selected.view(torch.int32).cpu() == 0x7fc00000).all())
+        else:
+            assert bool(torch.isfinite(grid).all())
+            assert max_abs(selected, ppg[rows].sum(0)) < 1e-6

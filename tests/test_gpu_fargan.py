@@ -178,3 +178,65 @@ def test_ragged_batch_is_exact(device, fargan_model, mode):
             if length < frames:
                 assert ragged[item, :, length * 256:].abs().max().item() == 0.
     model.model.kernel_mode = 0
+
+
+def test_auto_mode_timeout_fallback_and_rearm(
+    device, fargan_model, monkeypatch
+):
+    """Auto mode (kernel_mode 0) on a GPU that cannot keep the clusters
+    resident: the bounded exchange reports PM_ETIMEOUT (injected here through
+    pm_fargan_check while the cluster kernel is selected), the module retries
+    once, falls back to the one-workgroup-per-utterance kernel for RETRY_AFTER
+    calls and then tries the clusters again INSIDE the guarded path - the call
+    on which the counter reaches zero must not raise."""
+    import warnings
+    from promonet_amd import _lib
+    model = fargan_model('fp32')
+    fargan = model.model
+    inputs = on(device, oracle.synthetic_inputs(2, 6, seed=21))
+    with torch.inference_mode():
+        want = model(*inputs, None)
+    real = _lib.lib()
+    state = {'mode': 0, 'cluster_checks': 0, 'fail': True}
+
+    class Shim:
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def pm_fargan_set_mode(self, engine, mode):
+            state['mode'] = mode
+            return real.pm_fargan_set_mode(engine, mode)
+
+        def pm_fargan_check(self, *args):
+            code = real.pm_fargan_check(*args)
+            if state['mode'] != 1:
+                state['cluster_checks'] += 1
+                if state['fail']:
+                    return _lib.PM_ETIMEOUT
+            return code
+
+    monkeypatch.setattr(_lib, 'lib', lambda: Shim())
+    fargan.kernel_mode, fargan._fallback_calls = 0, 0
+    monkeypatch.setattr(type(fargan), 'RETRY_AFTER', 3)
+    try:
+        with torch.inference_mode(), warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            got = model(*inputs, None)              # 2 cluster tries, fallback
+            assert state['cluster_checks'] == 2 and fargan._fallback_calls == 3
+            assert max_abs(got, want) < 5e-6
+            for left in (2, 1, 0):                  # fallback kernel, no raise
+                got = model(*inputs, None)
+                assert fargan._fallback_calls == left
+                assert state['cluster_checks'] == 2
+            # counter at zero, GPU still shared: guarded retry, re-armed
+            got = model(*inputs, None)
+            assert state['cluster_checks'] == 4 and fargan._fallback_calls == 3
+            assert max_abs(got, want) < 5e-6
+            state['fail'] = False
+            for _ in range(3):
+                model(*inputs, None)
+            got = model(*inputs, None)              # clusters again, they hold
+            assert state['cluster_checks'] == 5 and fargan._fallback_calls == 0
+            assert max_abs(got, want) < 5e-6
+    finally:
+        fargan.kernel_mode, fargan._fallback_calls = 0, 0

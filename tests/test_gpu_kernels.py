@@ -1,7 +1,7 @@
 """GPU parity, per kernel: HIP path (through the C ABI) vs the CPU oracle on
-the same seeded inputs. Tolerances: fp32 operand mode is exact-fp32 MFMA
-(only the summation order differs from ATen) -> 2e-5 relative to the output
-scale; f16 operands (fp32 accumulate) -> 2e-3 relative per layer."""
+the same seeded inputs. fp32 operand mode is exact-fp32 MFMA (only the
+summation order differs from ATen); 16-bit operands accumulate in fp32. The
+gates are set from measurement (TOL* below)."""
 import ctypes
 
 import pytest
@@ -9,11 +9,19 @@ import torch
 import torch.nn.functional as F
 
 import restatement as oracle
-from util import from_cl, max_abs, pad32, rel_err, to_cl
+from util import check, from_cl, max_abs, pad32, rel_err, to_cl
 
 pytestmark = pytest.mark.gpu
 
-TOL = {'fp32': 2e-5, 'f16': 2e-3, 'bf16': 1.5e-2}
+# Gates, relative to the output's abs-max: <= 3x what MI355X measures
+# (profiles/r04/measured_errors.json, the ledger tests/util.py::check keeps) -
+# one conv pair: fp32 3.2e-6 / f16 2.5e-4 / bf16 2.1e-3; a whole Block or MRF
+# stage: 2.9e-6 / 4.3e-4 / 3.5e-3; the polyphase upsamplers (K = 2 C_in, one
+# rounding of a wide sum): 1.8e-6 / 4.3e-4 / 3.6e-3.
+TOL = {'fp32': 8e-6, 'f16': 6e-4, 'bf16': 5e-3}
+TOL_BLOCK = {'fp32': 8e-6, 'f16': 1.2e-3, 'bf16': 1e-2}
+TOL_MRF = {'fp32': 2.3e-6, 'f16': 7.5e-4, 'bf16': 6e-3}
+TOL_UP = {'fp32': 5e-6, 'f16': 1.2e-3, 'bf16': 1e-2}
 
 
 def lib():
@@ -69,7 +77,8 @@ def test_block_iteration(device, dtype, channels, kernel_size):
         want = block_iteration_oracle(x, w1, b1, w2, b2, kernel_size, d)
         got = run_block_iteration(
             device, dtype, x, w1, b1, w2, b2, kernel_size, d)
-        assert rel_err(got, want) < TOL[dtype], (d, length)
+        check(rel_err(got, want), TOL[dtype], f'iteration:{dtype}',
+              (channels, kernel_size, d, length))
 
 
 @pytest.mark.parametrize('channels', [4, 8, 16, 48])
@@ -82,7 +91,7 @@ def test_block_iteration_padded_channels(device, channels):
     b2 = torch.randn(channels, generator=gen)
     want = block_iteration_oracle(x, w1, b1, w2, b2, 7, 3)
     got = run_block_iteration(device, 'fp32', x, w1, b1, w2, b2, 7, 3)
-    assert rel_err(got, want) < TOL['fp32']
+    check(rel_err(got, want), TOL['fp32'], 'iteration_padded:fp32', channels)
 
 
 def test_block_iteration_short_and_modes(device):
@@ -98,17 +107,18 @@ def test_block_iteration_short_and_modes(device):
         x = torch.randn(3, c, length, generator=gen)
         want = block_iteration_oracle(x, w1, b1, w2, b2, k, 5)
         got = run_block_iteration(device, 'fp32', x, w1, b1, w2, b2, k, 5)
-        assert rel_err(got, want) < TOL['fp32'], length
+        check(rel_err(got, want), TOL['fp32'], 'iteration:fp32', length)
     x = torch.randn(2, c, 200, generator=gen)
     prev = torch.randn(2, c, 200, generator=gen)
     want = block_iteration_oracle(x, w1, b1, w2, b2, k, 1)
     got = run_block_iteration(
         device, 'fp32', x, w1, b1, w2, b2, k, 1, mode=1, scale=1 / 3)
-    assert rel_err(got, want / 3) < TOL['fp32']
+    check(rel_err(got, want / 3), TOL['fp32'], 'iteration:fp32', 'mode 1')
     got = run_block_iteration(
         device, 'fp32', x, w1, b1, w2, b2, k, 1, mode=2, scale=1 / 3,
         out_init=prev)
-    assert rel_err(got, prev + want / 3) < TOL['fp32']
+    check(rel_err(got, prev + want / 3), TOL['fp32'], 'iteration:fp32',
+          'mode 2')
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
@@ -177,8 +187,8 @@ def test_whole_block(device, dtype, channels, kernel_size):
             channels, kernel_size, mode, 1 / 3, ws.data_ptr(), ws.numel(),
             _lib.stream()))
         torch.cuda.synchronize()
-        tolerance = TOL[dtype] * (3 if dtype != 'fp32' else 1)
-        assert rel_err(from_cl(out, channels), want) < tolerance, (length, mode)
+        check(rel_err(from_cl(out, channels), want), TOL_BLOCK[dtype],
+              f'block:{dtype}', (channels, kernel_size, length, mode))
 
 
 def block_fixture(channels, kernel_size, gen, device, prefix='p'):
@@ -242,7 +252,8 @@ def test_walked_whole_block(device, dtype, channels, kernel_size):
             error = rel_err(from_cl(out, channels), want)
             print(f'walked block C {channels} k {kernel_size} {dtype} nseg '
                   f'{nseg} L {length}: rel {error:.3e}')
-            assert error < 3 * TOL[dtype], (nseg, length, mode)
+            check(error, TOL_BLOCK[dtype], f'block:{dtype}',
+                  ('walked', channels, kernel_size, nseg, length, mode))
             if channels <= 128 and (channels, kernel_size) != (128, 7):
                 # bit-identical to the stand-alone (two-sided halo) tiling
                 _lib.check(_lib.lib().pm_debug_force(0, 0))
@@ -313,7 +324,8 @@ def test_skewed_whole_block(device, dtype, channels, kernel_size):
             error = rel_err(from_cl(out, channels), want)
             print(f'skewed block C {channels} k {kernel_size} {dtype} nseg '
                   f'{nseg} L {length}: rel {error:.3e}')
-            assert error < 3 * TOL[dtype], (nseg, length, mode)
+            check(error, TOL_BLOCK[dtype], f'block:{dtype}',
+                  ('skewed', channels, kernel_size, nseg, length, mode))
             if (channels, kernel_size) not in ((128, 11), (256, 7)):
                 # the walked / stand-alone tiling of the same Block (no scratch
                 # handed over): same arithmetic per column
@@ -362,7 +374,8 @@ def test_conv_transpose(device, dtype, c_in, c_out, rate):
             ws.numel(), _lib.stream()))
         torch.cuda.synchronize()
         _lib.check(_lib.lib().pm_debug_force(0, 0))
-        assert rel_err(from_cl(out, c_out), want) < TOL[dtype], (length, groups)
+        check(rel_err(from_cl(out, c_out), want), TOL_UP[dtype],
+              f'conv_transpose:{dtype}', (c_in, c_out, rate, length, groups))
 
 
 def test_out_conv_tanh(device):
@@ -378,7 +391,7 @@ def test_out_conv_tanh(device):
             _lib.ptr(x_cl), _lib.ptr(wd), _lib.ptr(out), 2, length, c,
             _lib.stream()))
         torch.cuda.synchronize()
-        assert max_abs(out[:, None], want) < 1e-5
+        check(max_abs(out[:, None], want), 6e-6, 'out_conv_tanh:fp32', (c, length))
 
 
 def test_fold_weight_norm(device):
@@ -436,7 +449,8 @@ def test_whole_mrf(device, dtype, channels):
             channels, ws.data_ptr(), ws.numel(), _lib.stream()))
         torch.cuda.synchronize()
         got = from_cl(out, channels).cpu()
-        assert rel_err(got, want) < 2 * TOL[dtype], (length, dtype)
+        check(rel_err(got, want), TOL_MRF[dtype], f'mrf:{dtype}',
+              (channels, length))
     if dtype != 'fp32':
         # the walked whole-MRF kernel (conv_mrf_walk_kernel), which the
         # launcher only takes from 8 tiles per segment on: forced, 2 and 3
@@ -458,7 +472,8 @@ def test_whole_mrf(device, dtype, channels):
                     torch.cuda.synchronize()
                     outs.append(out)
                 got = from_cl(outs[0], channels).cpu()
-                assert rel_err(got, want) < 2 * TOL[dtype], (nseg, length)
+                check(rel_err(got, want), TOL_MRF[dtype], f'mrf:{dtype}',
+                      ('walked', channels, nseg, length))
                 assert torch.equal(outs[0], outs[1]), (nseg, length)
         finally:
             _lib.check(_lib.lib().pm_debug_force(0, 0))
@@ -500,7 +515,8 @@ def test_input_conv(device, dtype, shape):
             c_in, c_out, ws.data_ptr(), ws.numel(), _lib.stream()))
         torch.cuda.synchronize()
         got = from_cl(out, c_out).cpu()
-        assert rel_err(got, want) < TOL[dtype], (batch, length)
+        check(rel_err(got, want), TOL[dtype], f'input_conv:{dtype}',
+              (shape, batch, length))
 
 
 def test_f16_operands_saturate(device):
@@ -523,7 +539,7 @@ def test_f16_operands_saturate(device):
     want = block_iteration_oracle(x, w1, b1, w2, b2, k, d)
     got = run_block_iteration(device, 'f16', x, w1, b1, w2, b2, k, d)
     assert torch.isfinite(got).all()
-    assert rel_err(got, want) < TOL['f16']
+    check(rel_err(got, want), TOL['f16'], 'iteration:f16', 'large activations')
     x[0, 5, 50] = 3e5                       # lrelu(x) = 3e5 > 65504
     x[0, 9, 120] = -6e5                     # lrelu(x) = -6e4: still finite
     got = run_block_iteration(device, 'f16', x, w1, b1, w2, b2, k, d)
@@ -535,4 +551,5 @@ def test_f16_operands_saturate(device):
         xt = torch.clamp(F.leaky_relu(xt, .1), max=65504.)
         xt = F.conv1d(xt, w2, b2, padding=oracle.get_padding(k, 1))
         return xt + x
-    assert rel_err(got, saturated_oracle()) < TOL['f16']
+    check(rel_err(got, saturated_oracle()), TOL['f16'], 'iteration:f16',
+          'saturated')

@@ -7,23 +7,32 @@ import pytest
 import torch
 
 import restatement as oracle
-from util import max_abs, rel_err
+from util import check, max_abs, rel_err
 
 pytestmark = pytest.mark.gpu
 
 GATE = {'fp32': 2e-6, 'f16': 1e-4, 'bf16': 1e-4}
-# relative to the output's abs-max, for the tiny test vocoders (below)
-RELATIVE = {'fp32': 2e-5, 'f16': 2e-3, 'bf16': 1.5e-2}
+# What the default configuration (random init, output abs-max 0.017) actually
+# measures on MI355X is 5e-8 / 3.1e-6 / 3.0e-5 (profiles/r04/measured_errors.json):
+# besides BASELINE.json's gate every default-config check is held to <= 3x that,
+# so a regression that triples the error fails here and not only at full size.
+TIGHT = {'fp32': 2e-7, 'f16': 9e-6, 'bf16': 8e-5}
+# relative to the output's abs-max, for the tiny test vocoders (below); the
+# 64-initial-channel fixture (4 channels in its last stage: few products per
+# output) measures 1.4e-6 / 7.6e-4 / 6.8e-3, the 32-channel conditioning
+# variants 3.3e-7 / 2.5e-4 / 1.4e-3
+RELATIVE_SMALL = {'fp32': 4e-6, 'f16': 2e-3, 'bf16': 1.5e-2}
+RELATIVE_VARIANT = {'fp32': 1e-6, 'f16': 7.5e-4, 'bf16': 4e-3}
 
 
-def gate(dtype, scale):
+def gate(dtype, scale, relative=RELATIVE_SMALL):
     """The 1e-4 max-abs gate is BASELINE.json's, stated for the default
     configuration (512 initial channels, random-init output abs-max 0.017) and
-    applied to it unchanged. The tiny vocoders of the reference-weight
-    fixtures (64 / 32 initial channels, outputs up to 0.45, far fewer products
-    averaged per output) are held to a bound relative to their output scale
-    instead - the per-layer tolerances of tests/test_gpu_kernels.py."""
-    return max(GATE[dtype], RELATIVE[dtype] * scale)
+    applied to it unchanged (plus TIGHT). The tiny vocoders of the
+    reference-weight fixtures (64 / 32 initial channels, outputs up to 0.45,
+    far fewer products averaged per output) are held to a bound relative to
+    their output scale instead, <= 3x what they measure."""
+    return relative[dtype] * scale
 
 
 def make_model(state, dtype, device):
@@ -63,7 +72,8 @@ def test_generator_matches_reference_golden(
         assert got.shape == entry['audio'].shape
         error = max_abs(got, entry['audio'])
         print(f'{dtype} {name}: max-abs {error:.3e}')
-        assert error < GATE[dtype]
+        check(error, min(GATE[dtype], TIGHT[dtype]), f'golden_default:{dtype}',
+              name)
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
@@ -92,7 +102,7 @@ def test_small_config_reference_weights(device, golden_small, dtype):
     error = max_abs(got, golden_small['audio'])
     scale = golden_small['audio'].abs().max().item()
     print(f'small {dtype}: max-abs {error:.3e} (abs-max {scale:.3e})')
-    assert error < gate(dtype, scale)
+    check(error / scale, gate(dtype, 1.), f'small_config_relative:{dtype}')
 
 
 def test_prepare_features_golden(device, golden_default, default_state):
@@ -156,6 +166,32 @@ def test_from_features_api(device, golden_default, default_state):
             inputs[0][0], inputs[1], inputs[2], inputs[3])     # no gpu
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
+def test_config1_two_second_from_features(device, default_state, dtype):
+    """BASELINE.json configs[0] on the HIP path: ONE synthetic 2 s utterance
+    (172 frames -> 44 032 samples) through promonet.synthesize.from_features
+    (synthesize/core.py:18-59), every sample against the CPU oracle. The
+    single-utterance call takes the latency (narrow-tile) variants of the
+    kernels, which the batch-32 tests never reach."""
+    import promonet_amd
+    frames = 172
+    model = make_model(default_state, dtype, device)
+    promonet_amd.synthesize.set_model(model, device)
+    inputs = oracle.synthetic_inputs(1, frames, seed=2024)
+    got = promonet_amd.synthesize.from_features(
+        inputs[0][0], inputs[1], inputs[2], inputs[3], speaker=3, gpu=0)
+    with torch.inference_mode():
+        want = oracle.generator_forward(
+            inputs[0], inputs[1], inputs[2], inputs[3],
+            torch.tensor([3]), torch.ones(1), torch.ones(1), default_state)[0]
+    assert got.dtype == torch.float32     # (returned on `gpu`, as the reference does)
+    assert got.shape == want.shape == (1, frames * 256)
+    error = max_abs(got, want)
+    print(f'config 1 (1 x {frames} frames, from_features) {dtype}: max-abs '
+          f'{error:.3e} (abs-max {want.abs().max().item():.3e})')
+    check(error, min(GATE[dtype], TIGHT[dtype]), f'config1_from_features:{dtype}')
+
+
 def test_batched_matches_single_and_is_deterministic(device, default_state):
     """Size-independent properties at a larger size than the oracle is
     comfortable with: every utterance of a batch equals the same utterance
@@ -204,7 +240,9 @@ def oracle_window(inputs, item, first, last, frames, state, halo=14):
     return audio[..., (first - lo) * 256:(last - lo) * 256]
 
 
-def check_windows(model, device, state, batch, frames, seed, gate, windows):
+def check_windows(
+    model, device, state, batch, frames, seed, gate, windows, kind
+):
     inputs = oracle.synthetic_inputs(batch, frames, seed=seed)
     with torch.inference_mode():
         full = model(*on(device, inputs), None)
@@ -225,7 +263,7 @@ def check_windows(model, device, state, batch, frames, seed, gate, windows):
         print(f'utterance {item} frames [{first}, {first + span}): '
               f'max-abs {error:.3e} (abs-max {want.abs().max().item():.3e})')
         worst = max(worst, error)
-    assert worst < gate, worst
+    check(worst, gate, kind)
     return full, inputs
 
 
@@ -238,7 +276,8 @@ def test_full_size_config3_windows(device, default_state):
     utterance equals its stand-alone synthesis bit for bit."""
     model = make_model(default_state, 'bf16', device)
     full, inputs = check_windows(
-        model, device, default_state, 32, 861, 1234, GATE['bf16'], windows=6)
+        model, device, default_state, 32, 861, 1234,
+        min(GATE['bf16'], TIGHT['bf16']), windows=6, kind='config3_windows:bf16')
     with torch.inference_mode():
         single = model(*[t[7:8] for t in on(device, inputs)], None)
     assert torch.equal(single[0], full[7])
@@ -249,7 +288,8 @@ def test_full_size_fp32_config2(device, default_state):
     fp32 MFMA): 4 windows against the CPU oracle at the 2e-6 gate."""
     model = make_model(default_state, 'fp32', device)
     check_windows(
-        model, device, default_state, 8, 430, 77, GATE['fp32'], windows=4)
+        model, device, default_state, 8, 430, 77,
+        min(GATE['fp32'], TIGHT['fp32']), windows=4, kind='config2_windows:fp32')
 
 
 def test_full_size_every_sample(device, default_state):
@@ -281,7 +321,10 @@ def test_full_size_every_sample(device, default_state):
         print(f'full size, all {want.numel()} samples, {dtype}: max-abs '
               f'{error:.3e} rms {rms:.3e} (abs-max {want.abs().max():.3e}, '
               f'rel_to_absmax {error / want.abs().max().item():.3e})')
-        assert error < 1e-4, dtype
+        check(error, min(1e-4, TIGHT[dtype]), f'full_size_max_abs:{dtype}')
+        # (rms: 8.2e-6 bf16 / 6.0e-7 f16 measured)
+        check(rms, {'bf16': 1.5e-5, 'f16': 1.8e-6}[dtype],
+              f'full_size_rms:{dtype}')
         del model
 
 
@@ -303,8 +346,8 @@ def test_precision_at_trained_scale(device, default_state):
         want = oracle.generator_forward(*inputs, state)
     scale = want.abs().max().item()
     assert .4 < scale < .6
-    # absolute bounds at this scale (measured: 2e-6 / 8e-5 / 1.2e-4 / 8e-4)
-    bounds = {'fp32': 1e-5, 'f16': 2e-4, 'bf16+bf16+bf16+f16': 3e-4,
+    # absolute bounds at this scale (measured: 2.0e-6 / 7.2e-5 / 1.2e-4 / 7.7e-4)
+    bounds = {'fp32': 6e-6, 'f16': 2e-4, 'bf16+bf16+bf16+f16': 3e-4,
               'bf16': 2e-3}
     errors = {}
     for dtype, bound in bounds.items():
@@ -314,7 +357,7 @@ def test_precision_at_trained_scale(device, default_state):
         errors[dtype] = max_abs(got, want)
         print(f'trained scale (peak {scale:.2f}) {dtype}: max-abs '
               f'{errors[dtype]:.3e} = {errors[dtype] / scale:.3e} of the peak')
-        assert errors[dtype] < bound, dtype
+        check(errors[dtype], bound, f'trained_scale_peak0.5:{dtype}')
         del model
     # the last stage's operand type decides: f16 there recovers f16 accuracy
     assert errors['bf16+bf16+bf16+f16'] < .4 * errors['bf16']
@@ -356,9 +399,10 @@ def test_conditioning_variants_golden(device, which, dtype):
     error = max_abs(audio, golden['audio'])
     scale = golden['audio'].abs().max().item()
     print(f'{which} {dtype}: max-abs {error:.3e} (abs-max {scale:.3f})')
+    check(error / scale, gate(dtype, 1., RELATIVE_VARIANT),
+          f'variant_relative:{dtype}', which)
     # this 32-channel vocoder's output is 27x larger than the default
     # config's (0.45 vs 0.017 abs-max): same relative precision
-    assert error < gate(dtype, scale)
 
 
 @pytest.mark.parametrize('method,threshold', [
@@ -602,7 +646,8 @@ def test_ragged_batch_is_exact(device, default_state):
     want = oracle.generator_forward(
         *[t[3:4, ..., :33].cpu() if t.ndim >= 2 else t[3:4].cpu()
           for t in inputs], default_state)
-    assert max_abs(ragged[3:4, :, :33 * 256], want) < GATE['f16']
+    check(max_abs(ragged[3:4, :, :33 * 256], want), TIGHT['f16'],
+          'ragged_vs_oracle:f16')
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'f16'])
@@ -675,7 +720,7 @@ def test_packed_interface(device, golden_default, default_state):
         unpacked = model.unpack_features(entry['packed'].to(device))
     assert audio.dtype == torch.float32
     assert audio.shape == entry['audio'].shape
-    assert max_abs(audio, entry['audio']) < GATE['fp32']
+    check(max_abs(audio, entry['audio']), TIGHT['fp32'], 'packed_interface:fp32')
     assert len(model.labels()) == entry['labels'] == 53
     assert torch.equal(unpacked[4].cpu(), inputs[4])
     # the export-time self test of the reference (generator.py:363-368)
