@@ -45,7 +45,9 @@ FARGAN_FLOP_PER_SAMPLE = 73_843
 # conv 256x520 + its GLU 256x256, 3 x (GRU 768x384 + 768x256 + GLU 256x256),
 # skip 256x1152 + GLU, output 64x256; + 1/4 of the per-frame conditioning net
 FARGAN_WEIGHTS = 2_246_656 + (2 * 371 * 371 + 512 * 371) // 4
-PEAK_TFLOPS = {'f16': 2500., 'bf16': 2500., 'fp32': 157.3}   # dense MFMA
+# dense MFMA peaks per USEFUL flop (f16x3: three MFMAs per product)
+PEAK_TFLOPS = {'f16': 2500., 'bf16': 2500., 'fp32': 157.3,
+               'f16x3': 2500. / 3}
 PEAK_HBM_GBS = 8000.
 # sustained register-resident MFMA rate on random operands under the power cap
 # (scripts/micro/mfma_shapes.hip, profiles/r02/micro_mfma_shapes.txt): what an MFMA
@@ -61,8 +63,10 @@ def parse_args():
     parser.add_argument('--model', default='hifigan',
                         choices=['hifigan', 'fargan'])
     parser.add_argument('--dtype', default=None,
-                        choices=['f16', 'bf16', 'fp32'],
-                        help='MFMA operand type (hifigan, default bf16) / '
+                        help='MFMA operand type f16|bf16|fp32|f16x3, or one per '
+                             'upsampling stage joined by + (hifigan, default '
+                             'bf16; f16+f16+f16+f16x3 = the trained-checkpoint '
+                             'mode, DESIGN.md section 3) / '
                              'stored weight type f16|fp32 (fargan, default '
                              'fp32; its math is always fp32)')
     parser.add_argument('--batch', type=int, default=32,
@@ -245,6 +249,27 @@ class Watchdog:
         if self.timer is not None:
             self.timer.cancel()
             self.timer = None
+
+
+def operand_type_of(label, dtype):
+    """The MFMA operand type a kernel label (`block_c128_k11`, `convT_c64_r2`,
+    `mrf_c32` ...) ran with when `dtype` names one type per stage."""
+    import re
+    parts = dtype.split('+')
+    if len(parts) == 1:
+        return parts[0]
+    match = re.search(r'_c(\d+)', label)
+    if not match:
+        return parts[0]
+    channels = int(match.group(1))
+    initial = promonet_amd.HIFIGAN_UPSAMPLE_INITIAL_SIZE
+    for stage in range(len(parts)):
+        # upsamplers are labelled with their input width, Blocks with the output's
+        width = initial >> stage if label.startswith('convT') \
+            else initial >> (stage + 1)
+        if width == channels:
+            return parts[stage]
+    return parts[0]
 
 
 def parse_profile(text):
@@ -563,6 +588,7 @@ def main():
             flops_per_launch = row['flops'] / row['launches']
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             traffic, measured_step_bytes, covered_ms = None, None, 0.
+            operand = operand_type_of(label, args.dtype)
             traffic_file = ROOT / 'profiles' / 'traffic.json'
             if traffic_file.exists() and args.batch == 32 and frames == 861:
                 table = json.loads(traffic_file.read_text())
@@ -582,18 +608,19 @@ def main():
                 'kernel': label,
                 'bound': 'mfma',
                 'achieved': achieved,
-                'peak': PEAK_TFLOPS[args.dtype],
+                'operands': operand,
+                'peak': PEAK_TFLOPS[operand],
                 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_TFLOPS[args.dtype],
+                'frac': achieved / PEAK_TFLOPS[operand],
                 'traffic': traffic,
                 'traffic_source': (
                     'profiles/traffic.json: rocprofv3 PMC of this build '
                     '(FETCH_SIZE x 2 + WRITE_SIZE, separate passes), not '
                     're-measured in this run' if traffic else None),
-                'sustained_peak': SUSTAINED_TFLOPS.get(args.dtype),
+                'sustained_peak': SUSTAINED_TFLOPS.get(operand),
                 'frac_of_sustained_peak': (
-                    achieved / SUSTAINED_TFLOPS[args.dtype]
-                    if args.dtype in SUSTAINED_TFLOPS else None),
+                    achieved / SUSTAINED_TFLOPS[operand]
+                    if operand in SUSTAINED_TFLOPS else None),
                 'avg_launch_ms': avg_ms,
                 'launches_per_step': row['launches'] // args.steps,
                 'algorithmic_flops_per_launch': flops_per_launch,
@@ -612,7 +639,7 @@ def main():
             result['whole_path'] = {
                 'tflops': per_gpu * FLOP_PER_SAMPLE / 1e12,
                 'frac_of_mfma_peak': per_gpu * FLOP_PER_SAMPLE / 1e12 /
-                                     PEAK_TFLOPS[args.dtype],
+                                     PEAK_TFLOPS[args.dtype.split('+')[0]],
                 # HBM bytes the kernels really moved per step (rocprofv3 PMC,
                 # FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic.json) over
                 # this run's step time: the ACHIEVED HBM rate

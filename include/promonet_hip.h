@@ -45,6 +45,9 @@ extern "C" {
 #define PM_F32 0            /* v_mfma_f32_32x32x2_f32   - exact fp32       */
 #define PM_F16 1            /* v_mfma_f32_32x32x16_f16                     */
 #define PM_BF16 2           /* v_mfma_f32_32x32x16_bf16                    */
+#define PM_F16X3 3          /* f16 operands split hi + lo, three MFMAs per
+                             * step: ~21 bits per factor (trained-scale
+                             * accuracy for the last stage)  */
 
 #define PM_MAX_STAGES 8
 #define PM_MAX_RESBLOCKS 4
@@ -65,9 +68,9 @@ typedef struct pm_hifigan_config {
     int resblock_kernel_sizes[PM_MAX_RESBLOCKS];
     int num_dilations;
     int resblock_dilations[PM_MAX_RESBLOCKS][PM_MAX_DILATIONS];
-    int compute_dtype;                /* PM_F32 | PM_F16 | PM_BF16         */
+    int compute_dtype;                /* PM_F32 | PM_F16 | PM_BF16 | PM_F16X3 */
     /* Per-stage override of the MFMA operand type (upsampler + MRF of stage
-     * i): 0 = compute_dtype, else 1 + PM_F32 | PM_F16 | PM_BF16. E.g. bf16
+     * i): 0 = compute_dtype, else 1 + PM_F32 | PM_F16 | PM_BF16 | PM_F16X3. E.g. bf16
      * for the wide stages and f16 for the last two, whose rounding reaches
      * the output most directly.                                           */
     int stage_compute_dtype[PM_MAX_STAGES];

@@ -49,7 +49,9 @@ static unsigned long long* g_timeline = nullptr;   // pm_debug_timeline
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
-static inline int esz(int dtype) { return dtype == PM_F32 ? 4 : 2; }
+static inline int esz(int dtype) {
+    return dtype == PM_F32 || dtype == PM_F16X3 ? 4 : 2;
+}
 
 // ---------------------------------------------------------------------------
 // dtype dispatch
@@ -64,6 +66,7 @@ static hipError_t launch_pair(
         case PM_F32: return pm_launch_pair<ElemF32>(C, K, a, s);
         case PM_F16: return pm_launch_pair<ElemF16>(C, K, a, s);
         case PM_BF16: return pm_launch_pair<ElemBF16>(C, K, a, s);
+        case PM_F16X3: return pm_launch_pair<ElemF16X3>(C, K, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -78,6 +81,7 @@ static hipError_t launch_block3(
         case PM_F32: return pm_launch_block3<ElemF32>(C, K, a, s);
         case PM_F16: return pm_launch_block3<ElemF16>(C, K, a, s);
         case PM_BF16: return pm_launch_block3<ElemBF16>(C, K, a, s);
+        case PM_F16X3: return pm_launch_block3<ElemF16X3>(C, K, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -88,6 +92,7 @@ static hipError_t launch_mrf(
         case PM_F32: return pm_launch_mrf<ElemF32>(C, a, s);
         case PM_F16: return pm_launch_mrf<ElemF16>(C, a, s);
         case PM_BF16: return pm_launch_mrf<ElemBF16>(C, a, s);
+        case PM_F16X3: return pm_launch_mrf<ElemF16X3>(C, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -115,6 +120,7 @@ static int pair_chunk(int dtype, int C) {
         case PM_F32: return pm_pair_chunk<ElemF32>(C);
         case PM_F16: return pm_pair_chunk<ElemF16>(C);
         case PM_BF16: return pm_pair_chunk<ElemBF16>(C);
+        case PM_F16X3: return pm_pair_chunk<ElemF16X3>(C);
     }
     return 0;
 }
@@ -125,6 +131,7 @@ static bool block3_supported(int dtype, int C, int K) {
         case PM_F32: return pm_block3_supported<ElemF32>(C, K);
         case PM_F16: return pm_block3_supported<ElemF16>(C, K);
         case PM_BF16: return pm_block3_supported<ElemBF16>(C, K);
+        case PM_F16X3: return pm_block3_supported<ElemF16X3>(C, K);
     }
     return false;
 }
@@ -142,6 +149,7 @@ static hipError_t launch_single(
         case PM_F32: return pm_launch_single<ElemF32>(kind, ch, cfg, a, s);
         case PM_F16: return pm_launch_single<ElemF16>(kind, ch, cfg, a, s);
         case PM_BF16: return pm_launch_single<ElemBF16>(kind, ch, cfg, a, s);
+        case PM_F16X3: return pm_launch_single<ElemF16X3>(kind, ch, cfg, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -157,6 +165,9 @@ static hipError_t launch_pack(int dtype, const PackArgs& a, hipStream_t s) {
             break;
         case PM_BF16:
             hipLaunchKernelGGL(pm_pack_kernel<ElemBF16>, dim3(grid), dim3(256), 0, s, a);
+            break;
+        case PM_F16X3:
+            hipLaunchKernelGGL(pm_pack_kernel<ElemF16X3>, dim3(grid), dim3(256), 0, s, a);
             break;
         default:
             return hipErrorInvalidValue;
@@ -212,6 +223,10 @@ static hipError_t pack_bias_step(
             hipLaunchKernelGGL(pm_pack_bias_step_kernel<ElemBF16>, grid, block,
                                0, s, bias, out, g.cout, mtiles, per_mt);
             break;
+        case PM_F16X3:
+            hipLaunchKernelGGL(pm_pack_bias_step_kernel<ElemF16X3>, grid, block,
+                               0, s, bias, out, g.cout, mtiles, per_mt);
+            break;
         default:
             return hipErrorInvalidValue;
     }
@@ -229,7 +244,7 @@ static hipError_t pad_bias(
 // Wide upsampler (conv_upsample_kernel): 16-bit operands, C_in 256 / 512,
 // 256-row M blocks whose tap window is uniform. Sets the single-chunk packing.
 static bool upsample_whole_k(int dtype, ConvGeom& g) {
-    if (dtype == PM_F32 || g.mode != 1) return false;
+    if (esz(dtype) == 4 || g.mode != 1) return false;
     if (g.cin_pad != 256 && g.cin_pad != 512) return false;
     if (g.M % 256 || ((g.r / 2) * g.cout_pad) % 64) return false;
     g.ch = g.cin_pad;
@@ -324,7 +339,7 @@ extern "C" const char* pm_last_error(void) { return g_error; }
 extern "C" int pm_hifigan_create(
     const pm_hifigan_config* c, pm_hifigan_t* out) {
     if (!c || !out) return fail(PM_EINVAL, "null argument");
-    if (c->compute_dtype < 0 || c->compute_dtype > 2)
+    if (c->compute_dtype < 0 || c->compute_dtype > PM_F16X3)
         return fail(PM_EINVAL, "compute_dtype %d unknown", c->compute_dtype);
     if (c->num_stages < 1 || c->num_stages > PM_MAX_STAGES ||
         c->num_resblocks < 1 || c->num_resblocks > PM_MAX_RESBLOCKS ||
@@ -345,7 +360,8 @@ extern "C" int pm_hifigan_create(
         }
     }
     for (int i = 0; i < c->num_stages; ++i)
-        if (c->stage_compute_dtype[i] < 0 || c->stage_compute_dtype[i] > 3)
+        if (c->stage_compute_dtype[i] < 0 ||
+            c->stage_compute_dtype[i] > 1 + PM_F16X3)
             return fail(PM_EINVAL, "stage_compute_dtype[%d] = %d unknown", i,
                         c->stage_compute_dtype[i]);
     auto* h = new pm_hifigan_s();

@@ -42,6 +42,22 @@ __device__ __forceinline__ float4 pm_lrelu4(float4 v) {
 // k-indices (l >> 5) * 8 + e, e = 0..7 - identical for A and B, so the sum
 // over k is complete whatever order the hardware consumes it in.
 // ---------------------------------------------------------------------------
+// What every single-value element type shares: a row of an LDS operand tile is
+// `channels * ESZ` bytes with channel c at byte c * ESZ, a packed weight stream
+// an array of lds_t. (ElemF16X3 below interleaves hi and lo parts instead.)
+#define PM_ELEM_COMMON(bias_split)                                            \
+    static constexpr bool BIAS_SPLIT = bias_split;                            \
+    /* four channels ch .. ch + 3 (ch % 4 == 0) of an LDS row */              \
+    __device__ static __forceinline__ void store4_at(                         \
+        char* rowp, int ch, float4 v) {                                       \
+        store4(rowp + ch * ESZ, v);                                           \
+    }                                                                         \
+    /* element `index` of a packed weight stream */                           \
+    __device__ static __forceinline__ void pack_store(                        \
+        void* out, long long index, float v) {                                \
+        reinterpret_cast<lds_t*>(out)[index] = cvt(v);                        \
+    }
+
 struct ElemF16 {
     typedef _Float16 lds_t;
     typedef half8 frag_t;
@@ -77,6 +93,7 @@ struct ElemF16 {
         return r;
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return (_Float16)v; }
+    PM_ELEM_COMMON(true)
     // bias step (pm_pack_bias_step_kernel): c += b[co] for every column
     __device__ static __forceinline__ void mma_bias(
         const frag_t& a, floatx16& c) {
@@ -108,6 +125,7 @@ struct ElemBF16 {
         return __builtin_bit_cast(uint2, __builtin_convertvector(w, bf16x4));
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return (__bf16)v; }
+    PM_ELEM_COMMON(true)
     __device__ static __forceinline__ void mma_bias(
         const frag_t& a, floatx16& c) {
         unsigned pair = 0x3f803f80u;            // {1.0bf16, 1.0bf16}
@@ -138,10 +156,74 @@ struct ElemF32 {
         *reinterpret_cast<float4*>(p) = v;
     }
     __device__ static __forceinline__ lds_t cvt(float v) { return v; }
+    PM_ELEM_COMMON(false)
     // k = 0 carries the bias (lanes 0-31), k = 1 (lanes 32-63) is zero
     __device__ static __forceinline__ void mma_bias(
         const frag_t& a, floatx16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.x, 1.f, c, 0, 0, 0);
+    }
+};
+
+// f16 operands SPLIT into hi + lo (v = hi + lo up to 2^-22 |v|): a k16 step is
+// THREE v_mfma_f32_32x32x16_f16 - hi x hi, lo x hi, hi x lo (the lo x lo term,
+// 2^-22 of the product, is dropped) - so a product carries ~21 bits of each
+// factor at 3/16 of the cost of the exact fp32 MFMA path. It exists for the
+// LAST upsampling stage of a trained checkpoint: there one f16 rounding of the
+// activations alone is 3e-4 of an output that peaks near 1 (DESIGN.md
+// section 3). Storage: the 8 consecutive k-elements of a fragment are 32
+// bytes, [8 x hi | 8 x lo] - the same 4 bytes per element as ElemF32, so every
+// tiling written for ESZ == 4 carries over.
+struct ElemF16X3 {
+    typedef _Float16 lds_t;
+    struct frag_t { half8 hi, lo; };
+    static constexpr int ESZ = 4;
+    static constexpr int ID = 3;
+    static constexpr bool BIAS_SPLIT = true;
+    __device__ static __forceinline__ void mma(
+        const frag_t& a, const frag_t& b, floatx16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    // hi = rn(v) saturated at the top of the f16 range, lo = rn(v - hi)
+    __device__ static __forceinline__ void split4(
+        float4 v, half4& hi, half4& lo) {
+        const pm_f4 w = {v.x, v.y, v.z, v.w};
+        const _Float16 big = (_Float16)65504.f;
+        const half4 top = {big, big, big, big};
+        hi = __builtin_elementwise_min(__builtin_convertvector(w, half4), top);
+        const pm_f4 rest = w - __builtin_convertvector(hi, pm_f4);
+        lo = __builtin_elementwise_min(
+            __builtin_convertvector(rest, half4), top);
+    }
+    // channels ch .. ch + 3 of an LDS row: the 8-channel group g = ch / 8 is 32
+    // bytes, hi parts first; ch % 8 selects the half of both parts
+    __device__ static __forceinline__ void store4_at(
+        char* rowp, int ch, float4 v) {
+        half4 hi, lo;
+        split4(v, hi, lo);
+        char* p = rowp + (ch >> 3) * 32 + (ch & 4) * 2;
+        *reinterpret_cast<half4*>(p) = hi;
+        *reinterpret_cast<half4*>(p + 16) = lo;
+    }
+    __device__ static __forceinline__ void pack_store(
+        void* out, long long index, float v) {
+        const _Float16 hi = (_Float16)v;
+        _Float16* p = reinterpret_cast<_Float16*>(out) +
+                      (index >> 3) * 16 + (index & 7);
+        p[0] = hi;
+        p[8] = (_Float16)(v - (float)hi);
+    }
+    __device__ static __forceinline__ lds_t cvt(float v) { return (_Float16)v; }
+    // the bias step's fragment carries hi(b), lo(b) in k = 0, 1 of its hi part
+    // (pack_store of the two values; the lo part of those is zero or tiny)
+    __device__ static __forceinline__ void mma_bias(
+        const frag_t& a, floatx16& c) {
+        unsigned pair = 0x3c003c00u;            // {1.0h, 1.0h}
+        asm volatile("" : "+v"(pair));
+        const pm_u4 bits = {pair, pair, pair, pair};
+        const half8 ones = __builtin_bit_cast(half8, bits);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, ones, c, 0, 0, 0);
     }
 };
 

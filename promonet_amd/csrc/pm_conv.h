@@ -91,8 +91,8 @@ struct ChunkStager {
             const int idx = tid + it * NT;
             const int row = idx / Q, q = idx % Q;
             if (row < XR) {
-                ET::store4(buf + row * STRIDE + q * 4 * ET::ESZ,
-                           LRELU ? pm_lrelu4(r[it]) : r[it]);
+                ET::store4_at(buf + row * STRIDE, q * 4,
+                              LRELU ? pm_lrelu4(r[it]) : r[it]);
             }
         }
     }
@@ -136,7 +136,10 @@ __device__ __forceinline__ void mma_taps(
     const typename ET::frag_t* __restrict__ wnext, Hook mid = Hook()) {
     typedef typename ET::frag_t frag_t;
     constexpr int NS = KT * KC;
-    constexpr int BD = PM_BDEPTH;
+    // (split-f16: fragments are twice as wide and a step is three MFMAs per
+    // tile; the second B buffer is what spilled in the whole-MRF kernel, and
+    // the SIMD's other wave covers the LDS round trip)
+    constexpr int BD = ET::ID == 3 ? 1 : PM_BDEPTH;
     static_assert(NS % G == 0, "group size must divide the step count");
     static_assert(NS >= BD, "fewer steps than B buffers");
     frag_t abuf[2][G][MTW];   // A (weights): one GROUP ahead, from L2
@@ -314,7 +317,7 @@ __device__ __forceinline__ void store_tile_lrelu_impl(
         for (int g4 = 0; g4 < 4; ++g4) {
             float4 q = pm_lrelu4(acc_quad(v, g4));
             if (MASK && zero) q = make_float4(0.f, 0.f, 0.f, 0.f);
-            ET::store4(rowp + (ch + 8 * g4 + 4 * lh) * ET::ESZ, q);
+            ET::store4_at(rowp, ch + 8 * g4 + 4 * lh, q);
         }
     }
 }
@@ -1059,7 +1062,10 @@ __device__ __forceinline__ void block3_body(
     // columns then read the first rows of `t`, finite values that only ever
     // reach columns of the right halo, which the next tile recomputes)
     constexpr int ROWS_A = NC + (WALK ? 1 : 2) * MA;
-    constexpr int G = (ET::ESZ == 4) ? 2 : KC;
+    // (weight-fragment prefetch depth in k16 steps; a split-f16 step is three
+    // MFMAs per tile - 192+ cycles at two tiles per wave -, so one step ahead
+    // covers the L2 round trip and depth 2 spilled at C = 32 k 11)
+    constexpr int G = (ET::ESZ == 4) ? (ET::ID == 3 ? 1 : 2) : KC;
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;          // bias step of a stream
     constexpr int W_MT_STRIDE = W_BIAS + 64;
@@ -1495,12 +1501,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_kernel(MrfArgs m) {
         // pressure and runs before the sum is live
         // (the three Blocks start from the same x tile - the launcher checks
         // - and each requests it for the next one under its last conv2)
+        // (split-f16 operands: fragments are twice as wide and the kernel is
+        // MFMA-bound - no registers for the hand-over, every Block reads its
+        // x tile itself, out of L2)
+        constexpr int XN = ET::ID == 3 ? 0 : 1;
         floatx16 xnext[(C / 32) / WM][NTW];
-        block3_body<ET, C, 11, WM, WN, NTW, 1, 2>(m.k[2], smem, sum, xnext);
+        block3_body<ET, C, 11, WM, WN, NTW, 1, 2 * XN>(m.k[2], smem, sum, xnext);
         pm_block_sync();
-        block3_body<ET, C, 7, WM, WN, NTW, 2, 3>(m.k[1], smem, sum, xnext);
+        block3_body<ET, C, 7, WM, WN, NTW, 2, 3 * XN>(m.k[1], smem, sum, xnext);
         pm_block_sync();
-        block3_body<ET, C, 3, WM, WN, NTW, 3, 1>(m.k[0], smem, sum, xnext);
+        block3_body<ET, C, 3, WM, WN, NTW, 3, 1 * XN>(m.k[0], smem, sum, xnext);
     } else {
         block3_body<ET, C, 3, WM, WN, NTW>(m.k[0], smem, sum, sum);
         pm_block_sync();

@@ -1,0 +1,11 @@
+// Explicit instantiation of the MFMA convolution launchers for ElemF16X3 (f16
+// operands split into hi + lo, three MFMAs per k16 step - pm_common.h).
+#define PM_INSTANTIATE
+#include "pm_launch.h"
+template hipError_t pm_launch_pair<ElemF16X3>(int, int, const PairArgs&, hipStream_t);
+template int pm_pair_tile_len<ElemF16X3>(int, int);
+template hipError_t pm_launch_single<ElemF16X3>(int, int, int, const SingleArgs&, hipStream_t);
+template hipError_t pm_launch_block3<ElemF16X3>(int, int, const Block3Args&, hipStream_t);
+template hipError_t pm_launch_mrf<ElemF16X3>(int, const Block3Args (&)[3], hipStream_t);
+template int pm_pair_chunk<ElemF16X3>(int);
+template bool pm_block3_supported<ElemF16X3>(int, int);

@@ -134,6 +134,9 @@ template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1, CH = 
 template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
 template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
 template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
+// split f16 (hi + lo, three MFMAs per step): 4 bytes per element like fp32,
+// the same tiles
+template <int C> struct PairCfg<ElemF16X3, C> : PairCfg<ElemF32, C> {};
 
 // Latency variant: when the wide tiling yields fewer workgroups than the chip
 // has CUs (single utterances: 8 tiles at C = 256 for 2 s of audio), 64-column
@@ -263,6 +266,7 @@ template <> struct Block3Cfg<ElemF32, 32, 11>  { enum { WM = 1, WN = 8, NTW = 2 
 template <> struct Block3Cfg<ElemF32, 64, 3>   { enum { WM = 2, WN = 4, NTW = 2 }; };
 template <> struct Block3Cfg<ElemF32, 64, 7>   { enum { WM = 2, WN = 4, NTW = 2 }; };
 template <> struct Block3Cfg<ElemF32, 64, 11>  { enum { WM = 2, WN = 4, NTW = 2 }; };
+template <int C, int K> struct Block3Cfg<ElemF16X3, C, K> : Block3Cfg<ElemF32, C, K> {};
 
 // Latency variants (see PairCfgNarrow): half the waves, same per-wave tile.
 template <class ET, int C, int K> struct Block3CfgNarrow : Block3Cfg<ET, C, K> {};

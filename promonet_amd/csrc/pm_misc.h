@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void pm_pack_kernel(PackArgs a) {
     }
     // with bias steps the stream of M tile mt is 512 elements longer
     const long long dst = idx + (a.bias_step ? (long long)mt * 512 : 0);
-    reinterpret_cast<typename ET::lds_t*>(a.out)[dst] = ET::cvt(v);
+    ET::pack_store(a.out, dst, v);
 }
 
 // The conv bias as one more k16 step of the weight stream ("bias step", the
@@ -96,16 +96,17 @@ __global__ __launch_bounds__(256) void pm_pack_bias_step_kernel(
     const int mt = idx / 512, r = idx % 512;
     const int lane = r / 8, e = r % 8;
     const int co = mt * 32 + (lane & 31);
-    typedef typename ET::lds_t T;
-    T v = ET::cvt(0.f);
+    // (k = 0: the bias rounded to the operand type; k = 1, 16-bit types: what
+    // the rounding left - the MFMA against ones adds both)
+    float v = 0.f;
     if (lane < 32 && co < cout) {
         const float b = bias[co];
-        const T hi = ET::cvt(b);
-        if (e == 0) v = hi;
-        if (e == 1 && ET::ESZ == 2) v = ET::cvt(b - (float)hi);
+        const float hi = (float)ET::cvt(b);
+        if (e == 0) v = ET::BIAS_SPLIT ? hi : b;
+        if (e == 1 && ET::BIAS_SPLIT) v = b - hi;
     }
-    reinterpret_cast<T*>(out)[(long long)mt * (weights_per_mt + 512) +
-                              weights_per_mt + r] = v;
+    ET::pack_store(out, (long long)mt * (weights_per_mt + 512) +
+                            weights_per_mt + r, v);
 }
 
 // dst[i] = i < n ? src[i] : 0  for i < n_pad; optionally tiled `rep` times

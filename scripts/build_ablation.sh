@@ -12,6 +12,6 @@ for v in A B AB; do
 done
 wait
 for v in A B AB; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/obj/pm_api.o build/obj/pm_conv_f16_no$v.o build/obj/pm_conv_bf16.o build/obj/pm_conv_f32.o build/obj/pm_conv_f16_mrf.o build/obj/pm_conv_bf16_mrf.o -o promonet_amd/lib/libpromonet_hip_no$v.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/obj/pm_api.o build/obj/pm_conv_f16_no$v.o build/obj/pm_conv_bf16.o build/obj/pm_conv_f32.o build/obj/pm_conv_f16x3.o build/obj/pm_conv_f16_mrf.o build/obj/pm_conv_bf16_mrf.o -o promonet_amd/lib/libpromonet_hip_no$v.so
 done
 ls -la promonet_amd/lib

@@ -16,7 +16,8 @@ GATE = {'fp32': 2e-6, 'f16': 1e-4, 'bf16': 1e-4}
 # measures on MI355X is 5e-8 / 3.1e-6 / 3.0e-5 (profiles/r04/measured_errors.json):
 # besides BASELINE.json's gate every default-config check is held to <= 3x that,
 # so a regression that triples the error fails here and not only at full size.
-TIGHT = {'fp32': 2e-7, 'f16': 9e-6, 'bf16': 8e-5}
+TIGHT = {'fp32': 2e-7, 'f16': 9e-6, 'bf16': 8e-5, 'f16+f16+f16+f16x3': 9e-7}
+GATE['f16+f16+f16+f16x3'] = 1e-4
 # relative to the output's abs-max, for the tiny test vocoders (below); the
 # 64-initial-channel fixture (4 channels in its last stage: few products per
 # output) measures 1.4e-6 / 7.6e-4 / 6.8e-3, the 32-channel conditioning
@@ -56,7 +57,7 @@ def on(device, inputs):
     return [t.to(device) for t in inputs]
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'f16', 'bf16', 'f16+f16+f16+f16x3'])
 def test_generator_matches_reference_golden(
     device, golden_default, default_state, dtype
 ):
@@ -347,8 +348,8 @@ def test_precision_at_trained_scale(device, default_state):
     scale = want.abs().max().item()
     assert .4 < scale < .6
     # absolute bounds at this scale (measured: 2.0e-6 / 7.2e-5 / 1.2e-4 / 7.7e-4)
-    bounds = {'fp32': 6e-6, 'f16': 2e-4, 'bf16+bf16+bf16+f16': 3e-4,
-              'bf16': 2e-3}
+    bounds = {'fp32': 6e-6, 'f16+f16+f16+f16x3': 3.5e-5, 'f16': 2e-4,
+              'bf16+bf16+bf16+f16': 3e-4, 'bf16': 2e-3}
     errors = {}
     for dtype, bound in bounds.items():
         model = make_model(state, dtype, device)
@@ -361,7 +362,44 @@ def test_precision_at_trained_scale(device, default_state):
         del model
     # the last stage's operand type decides: f16 there recovers f16 accuracy
     assert errors['bf16+bf16+bf16+f16'] < .4 * errors['bf16']
-    assert errors['fp32'] < errors['f16'] < errors['bf16']
+    assert errors['fp32'] < errors['f16+f16+f16+f16x3'] < errors['f16'] \
+        < errors['bf16']
+
+
+def test_trained_checkpoint_mode_holds_the_gate_near_full_scale(
+    device, default_state
+):
+    """The operand mode INTEGRATION.md names for real checkpoints -
+    'f16+f16+f16+f16x3': f16 MFMA operands, split into hi + lo (three MFMAs per
+    step) in the last upsampling stage - holds BASELINE.json's 1e-4 max-abs
+    gate with the output conv rescaled so that the audio peaks at 0.99 (a
+    trained generator's scale; random init peaks at 0.017), on every sample of
+    batch 4 x 4 s. Plain f16 does not (3e-4: one rounding of the last stage's
+    activations), which is what the split exists for; exact fp32 operands do,
+    at 8x the step time."""
+    import math
+    inputs = oracle.synthetic_inputs(4, 344, seed=99)
+    with torch.inference_mode():
+        peak = oracle.generator_forward(*inputs, default_state).abs().max()
+    state = dict(default_state)
+    state['model.model.5.weight'] = state['model.model.5.weight'] * (
+        math.atanh(.99) / math.atanh(float(peak)))
+    with torch.inference_mode():
+        want = oracle.generator_forward(*inputs, state)
+    scale = want.abs().max().item()
+    assert .98 < scale < 1.
+    errors = {}
+    for dtype in ('f16+f16+f16+f16x3', 'f16', 'fp32'):
+        model = make_model(state, dtype, device)
+        with torch.inference_mode():
+            got = model(*on(device, inputs), None)
+        errors[dtype] = max_abs(got, want)
+        print(f'trained scale (peak {scale:.3f}) {dtype}: max-abs '
+              f'{errors[dtype]:.3e}')
+        del model
+    check(errors['f16+f16+f16+f16x3'], 1e-4, 'trained_scale_peak0.99:f16x3')
+    check(errors['fp32'], 3e-5, 'trained_scale_peak0.99:fp32')
+    assert errors['f16'] > 1e-4       # (why the mode exists)
 
 
 ###############################################################################
