@@ -139,7 +139,7 @@ __device__ __forceinline__ void mma_taps(
     // (split-f16: fragments are twice as wide and a step is three MFMAs per
     // tile; the second B buffer is what spilled in the whole-MRF kernel, and
     // the SIMD's other wave covers the LDS round trip)
-    constexpr int BD = ET::ID == 3 ? 1 : PM_BDEPTH;
+    constexpr int BD = ET::ID == 3 && NTW >= 2 ? 1 : PM_BDEPTH;
     static_assert(NS % G == 0, "group size must divide the step count");
     static_assert(NS >= BD, "fewer steps than B buffers");
     frag_t abuf[2][G][MTW];   // A (weights): one GROUP ahead, from L2
@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void block3_body(
     // (weight-fragment prefetch depth in k16 steps; a split-f16 step is three
     // MFMAs per tile - 192+ cycles at two tiles per wave -, so one step ahead
     // covers the L2 round trip and depth 2 spilled at C = 32 k 11)
-    constexpr int G = (ET::ESZ == 4) ? (ET::ID == 3 ? 1 : 2) : KC;
+    constexpr int G = (ET::ESZ == 4) ? (ET::ID == 3 && NTW >= 2 ? 1 : 2) : KC;
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;          // bias step of a stream
     constexpr int W_MT_STRIDE = W_BIAS + 64;

@@ -427,7 +427,10 @@ static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stre
     }
     // Walked variant (no left-halo recompute): one workgroup per (utterance,
     // segment) with enough tiles per segment to amortise its two-sided first
-    // tile; the sum-in-registers geometry (C = 32) only.
+    // tile; the sum-in-registers geometry (C = 32) only. (Split-f16 operands,
+    // 4 bytes per element in LDS: the carry areas only fit beside 256-column
+    // tiles of one tile per wave, and that walked variant measured 8.4 ms
+    // against 7.0 ms for the stand-alone 512-column tiling - round 4, not kept.)
     if constexpr (C == 32 && ET::ESZ == 2 && WM * WN == 8) {
         const int cus = pm_device_cus();
         const int forced = pm_force().walk_nseg;

@@ -452,7 +452,7 @@ def test_whole_mrf(device, dtype, channels):
         got = from_cl(out, channels).cpu()
         check(rel_err(got, want), TOL_MRF[dtype], f'mrf:{dtype}',
               (channels, length))
-    if dtype in ('f16', 'bf16'):
+    if dtype != 'fp32':
         # the walked whole-MRF kernel (conv_mrf_walk_kernel), which the
         # launcher only takes from 8 tiles per segment on: forced, 2 and 3
         # segments, ragged segment ends; bit-identical to the stand-alone tiling
