@@ -736,6 +736,10 @@ static int forward_impl(
         });
     }
     int xi = 0;        // index of the buffer holding the stage input
+    // the stage input once more, as the 16-bit operand values of the next
+    // upsampler (written by the previous stage's last Block launch when that
+    // is a skewed walk - Block3Args::act16), or null
+    const void* x16 = nullptr;
     int L = T;
     int rate = 1;      // samples per frame at the current stage
     const float scale = 1.f / (float)h->cfg.num_resblocks;
@@ -749,6 +753,8 @@ static int forward_impl(
             a.M = st.up.geom.M; a.lrelu = 1; a.pad = 1;
             a.phase_c = st.cout_pad; a.phase_p = st.r / 2; a.phase_r = st.r;
             a.lengths = lengths; a.len_scale = rate;
+            a.x16 = x16;
+            x16 = nullptr;
             char label[64];
             snprintf(label, sizeof(label), "convT_c%d_r%d", st.cin, st.r);
             PROF(h, s, label, 2.0 * st.cin * st.cout * st.k * B * L,
@@ -813,6 +819,22 @@ static int forward_impl(
                 a.lengths = lengths; a.len_scale = rate;
                 a.scratch = p.scratch ? base + p.off_scratch : nullptr;
                 a.scratch_bytes = p.scratch;
+                // The stage's last Block launch completes `out`, whose only
+                // reader is the next stage's upsampler - which stages
+                // cvt(lrelu(out)): let the kernel write exactly that (half the
+                // bytes out, half the bytes in, no staging VALU) when the
+                // upsampler is the conv_single_kernel of a 16-bit stage.
+                int act16_done = 0;
+                const size_t si_index = &st - &h->stages[0];
+                if (j == h->cfg.num_resblocks - 1 && a.mode == 2 &&
+                    si_index + 1 < h->stages.size()) {
+                    const Stage& next = h->stages[si_index + 1];
+                    if (esz(next.dtype) == 2 && next.up.cfg != 4) {
+                        a.act16 = buf[ai];      // (free: no pair iterations)
+                        a.act16_type = next.dtype;
+                        a.act16_done = &act16_done;
+                    }
+                }
                 char label[64];
                 snprintf(label, sizeof(label), "block_c%d_k%d", st.cout, K);
                 hipError_t e = hipSuccess;
@@ -823,6 +845,7 @@ static int forward_impl(
                 });
                 fused = e == hipSuccess;
                 if (!fused && h->profile) h->marks.pop_back();
+                if (fused && act16_done) x16 = buf[ai];
             }
             if (fused) continue;
             const float* src = buf[ui];

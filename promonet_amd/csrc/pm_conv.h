@@ -82,6 +82,44 @@ struct ChunkStager {
         }
     }
 
+    // The same tile from a tensor that already holds the operand values
+    // (16-bit, activation applied by the kernel that produced it - the
+    // skewed whole-Block walk's `act16` output): half the bytes, no VALU.
+    static constexpr int Q16 = CH / 8;  // 16-byte pieces per row-chunk
+    static constexpr int MAXIT16 = (XR_MAX * Q16 + NT - 1) / NT;
+    static_assert(MAXIT16 <= MAXIT, "register budget of the 16-bit path");
+    __device__ __forceinline__ void load16(
+        const void* __restrict__ xb16, int cstride, int c0, int t_first,
+        int XR, int L, int tid) {
+        const int lo = max(t_first, 0);
+        const int hi = min(L, t_first + XR);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(xb16)) +
+                (size_t)lo * cstride * 2, 0,
+            max(hi - lo, 0) * cstride * 2, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < MAXIT16; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx / Q16, q = idx % Q16;
+            const unsigned voff = (unsigned)(
+                ((t_first - lo + row) * cstride + c0 + q * 8) * 2);
+            const pm_u4 v =
+                __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+            r[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y),
+                                __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    }
+    template <int STRIDE = S>
+    __device__ __forceinline__ void store16(char* buf, int XR, int tid) {
+#pragma unroll
+        for (int it = 0; it < MAXIT16; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx / Q16, q = idx % Q16;
+            if (row < XR)
+                *reinterpret_cast<float4*>(buf + row * STRIDE + q * 16) = r[it];
+        }
+    }
+
     // Registers -> LDS with the input activation and operand conversion fused
     // (STRIDE: LDS row pitch, when the chunk is a slab of a wider tile)
     template <bool LRELU, int STRIDE = S>
@@ -618,6 +656,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
 // ---------------------------------------------------------------------------
 
 struct SingleArgs {
+    const void* x16;      // (B, L, Cin) operand-type copy of act(x), or null:
+                          // staged as it is instead of x (16-bit types only)
     const float* x;       // (B, L, Cin) fp32
     float* out;           // (B, L, M) fp32  (for ConvTranspose: (B, L*r, Cout))
     const void* w;        // packed weights, KT taps per M tile
@@ -702,9 +742,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     ChunkStager<ET, CH, NT, XR> stager;
-    stager.load(xb, Cin, 0, t_first, XR, L, tid);
-    if (a.lrelu) stager.template store<true>(smem, XR, tid);
-    else stager.template store<false>(smem, XR, tid);
+    // (x16: the producer already wrote the operand values - see SingleArgs)
+    bool pre = false;
+    const char* xb16 = nullptr;
+    if constexpr (ET::ESZ == 2) {
+        pre = a.x16 != nullptr;
+        xb16 = reinterpret_cast<const char*>(a.x16) + (size_t)b * a.L * Cin * 2;
+    }
+    if (pre) {
+        stager.load16(xb16, Cin, 0, t_first, XR, L, tid);
+        stager.store16(smem, XR, tid);
+    } else {
+        stager.load(xb, Cin, 0, t_first, XR, L, tid);
+        if (a.lrelu) stager.template store<true>(smem, XR, tid);
+        else stager.template store<false>(smem, XR, tid);
+    }
     pm_block_sync();
 
     const int w_mt_stride = NCH * KT * KC * 64;
@@ -718,15 +770,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
         char* cur = smem + (c & 1) * XR * SX;
-        if (c + 1 < NCH)
-            stager.load(xb, Cin, (c + 1) * CH, t_first, XR, L, tid);
+        if (c + 1 < NCH) {
+            if (pre) stager.load16(xb16, Cin, (c + 1) * CH, t_first, XR, L, tid);
+            else stager.load(xb, Cin, (c + 1) * CH, t_first, XR, L, tid);
+        }
         mma_taps<ET, KT, KC, MTW, NTW, G, SX>(
             acc, cur + lane_off_x, SX, w + (size_t)c * (KT * KC * 64),
             w_mt_stride, afirst,
             c + 1 < NCH ? w + (size_t)(c + 1) * (KT * KC * 64) : nullptr);
         if (c + 1 < NCH) {
             char* nxt = smem + ((c + 1) & 1) * XR * SX;
-            if (a.lrelu) stager.template store<true>(nxt, XR, tid);
+            if (pre) stager.store16(nxt, XR, tid);
+            else if (a.lrelu) stager.template store<true>(nxt, XR, tid);
             else stager.template store<false>(nxt, XR, tid);
             pm_block_sync();
         }
@@ -996,6 +1051,14 @@ struct Block3Args {
     int len_scale;
     char* scratch;       // device scratch for the skewed walk, or null
     size_t scratch_bytes;
+    // Optional (skewed walk only): instead of the fp32 tensor `out`, store
+    // cvt(lrelu(result)) as the 16-bit MFMA operand type `act16_type` (PM_F16 /
+    // PM_BF16 numbering) - what the next stage's upsampler, the only reader
+    // of a stage's output, stages anyway. *act16_done (host) is set to 1 by
+    // the launcher when the kernel it took honours the request.
+    void* act16;
+    int act16_type;
+    int* act16_done;
     PM_TIMELINE_FIELD    // debug stamps (tuning builds)
 };
 
@@ -2176,6 +2239,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
             max(own_n, 0) * C * 4, 0x00020000);
         const unsigned ovoff0 = (unsigned)(
             ((o - own_first + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
+        const bool a16 = a.act16 != nullptr;
+        const bool a16f = a.act16_type == 1;       // PM_F16, else PM_BF16
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(a.act16) +
+                ((size_t)b * a.L + own_first) * C * 2, 0,
+            a16 ? max(own_n, 0) * C * 2 : 0, 0x00020000);
         // (MRF accumulation: the reads of `out` of up to four tiles go out
         // before the first store - the operand pipeline's registers are free
         // here -, one HBM round trip per step instead of one per tile)
@@ -2203,19 +2272,48 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
                 const int mt = (t0 + i) / NTW, nt = (t0 + i) % NTW;
                 const unsigned voff =
                     ovoff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+                float4 rq[4];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    pm_u4 r;
-                    r.x = __float_as_uint(__uint_as_float(old[i][g4].x) +
-                                          trunk[mt][nt][4 * g4 + 0] * sc);
-                    r.y = __float_as_uint(__uint_as_float(old[i][g4].y) +
-                                          trunk[mt][nt][4 * g4 + 1] * sc);
-                    r.z = __float_as_uint(__uint_as_float(old[i][g4].z) +
-                                          trunk[mt][nt][4 * g4 + 2] * sc);
-                    r.w = __float_as_uint(__uint_as_float(old[i][g4].w) +
-                                          trunk[mt][nt][4 * g4 + 3] * sc);
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        r, orsrc, voff + g4 * 32, 0, 0);
+                for (int g4 = 0; g4 < 4; ++g4)
+                    rq[g4] = make_float4(
+                        __uint_as_float(old[i][g4].x) +
+                            trunk[mt][nt][4 * g4 + 0] * sc,
+                        __uint_as_float(old[i][g4].y) +
+                            trunk[mt][nt][4 * g4 + 1] * sc,
+                        __uint_as_float(old[i][g4].z) +
+                            trunk[mt][nt][4 * g4 + 2] * sc,
+                        __uint_as_float(old[i][g4].w) +
+                            trunk[mt][nt][4 * g4 + 3] * sc);
+                if (a16) {
+                    // the stage's output as the next upsampler's operand:
+                    // lrelu, 16-bit, 8 consecutive channels per lane (the
+                    // half-wave exchange of store_tile_lrelu_impl)
+                    const unsigned v16 = (voff - 16u * lh) / 2;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; g4 += 2) {
+                        const float4 lo = pm_lrelu4(rq[g4]);
+                        const float4 hi = pm_lrelu4(rq[g4 + 1]);
+                        const uint2 pa = a16f ? ElemF16::pack4(lo)
+                                              : ElemBF16::pack4(lo);
+                        const uint2 pb = a16f ? ElemF16::pack4(hi)
+                                              : ElemBF16::pack4(hi);
+                        auto sx = __builtin_amdgcn_permlane32_swap(
+                            pa.x, pb.x, false, false);
+                        auto sy = __builtin_amdgcn_permlane32_swap(
+                            pa.y, pb.y, false, false);
+                        const pm_u4 u = {sx[0], sy[0], sx[1], sy[1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            u, arsrc, v16 + 16 * (g4 + lh), 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const pm_u4 r = {
+                            __float_as_uint(rq[g4].x), __float_as_uint(rq[g4].y),
+                            __float_as_uint(rq[g4].z), __float_as_uint(rq[g4].w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            r, orsrc, voff + g4 * 32, 0, 0);
+                    }
                 }
             }
         }

@@ -316,6 +316,8 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
             const size_t need = (size_t)a.B * nseg * GE::SCRATCH;
             if ((forced || (a.L / NC) / nseg >= 4) && need <= a.scratch_bytes) {
                 Block3SkewArgs p;
+                if (a.act16 && a.act16_done) *a.act16_done = 1;
+                a.act16_done = nullptr;     // (a host pointer)
                 p.a = a; p.nseg = nseg; p.wg_scratch = GE::SCRATCH;
                 p.scratch = a.scratch;
                 auto skew = conv_block3_skew_kernel<ET, C, K, WM, WN, NTW>;
@@ -328,6 +330,7 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
             }
         }
     }
+    a.act16 = nullptr; a.act16_done = nullptr;   // (the skewed walk only)
     // Walked variant (no left-halo recompute) for grids that fill the chip
     // several times over, where its carry area (halo rows) fits the LDS
     if constexpr (ET::ESZ == 2 && WM * WN == 8 && !(C == 128 && K == 11) &&
