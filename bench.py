@@ -76,6 +76,10 @@ def parse_args():
                         help='seconds of back-to-back steps timed after the '
                              'K official ones (steady-state clocks); 0 = off')
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--no-traffic', action='store_true',
+                        help='skip the two rocprofv3 PMC passes that measure '
+                             'the HBM traffic of every kernel (roofline.traffic '
+                             'then comes from profiles/traffic.json)')
     parser.add_argument('--no-gather', action='store_true')
     return parser.parse_args()
 
@@ -270,6 +274,89 @@ def operand_type_of(label, dtype):
         if width == channels:
             return parts[stage]
     return parts[0]
+
+
+def kernel_label(name):
+    """rocprofv3 kernel name -> the label the engine's profile report uses."""
+    import re
+    name = name.replace(' ', '').replace('Elem', '')
+    m = re.search(r'conv_pair_kernel<\w+,(\d+),(\d+),', name)
+    if m:
+        return f'pair_c{m.group(1)}_k{m.group(2)}'
+    m = re.search(r'conv_block3(?:_walk|_skew)?_kernel<\w+,(\d+),(\d+),', name)
+    if m:
+        return f'block_c{m.group(1)}_k{m.group(2)}'
+    m = re.search(r'conv_mrf(?:_walk)?_kernel<\w+,(\d+),', name)
+    if m:
+        return f'mrf_c{m.group(1)}'
+    if 'pm_out_conv' in name:
+        return 'out_conv_tanh'
+    if re.search(r'conv_single_kernel<\w+,7,7,', name):
+        return 'input_conv'
+    m = re.search(r'conv_upsample_kernel<\w+,(\d+),', name)
+    if m:
+        return f'convT_c{m.group(1)}_r8'
+    if re.search(r'conv_single_kernel<\w+,2,3,64,4,2,1,2,0>', name):
+        return 'convT_c128_r2'
+    if re.search(r'conv_single_kernel<\w+,2,3,64,2,2,1,2,0>', name):
+        return 'convT_c64_r2'
+    return None
+
+
+def measure_traffic(args, timeout=150.):
+    """HBM bytes per launch of every kernel of the step, MEASURED in this run:
+    two rocprofv3 PMC passes (FETCH_SIZE, then WRITE_SIZE - they do not fit one
+    pass: MI355X_MICROARCH.md, rocprofv3 PMC slots) over one step of this very
+    command. bytes = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024: both counters are in
+    KiB and on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
+    (the guide's HBM section). Returns ({label: bytes}, note) or (None, why)."""
+    import csv
+    import shutil
+    import tempfile
+    tool = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not Path(tool).exists():
+        return None, 'rocprofv3 not found'
+    command = [
+        sys.executable, str(Path(__file__).resolve()), '--steps', '1',
+        '--warmup', '1', '--sustain', '0', '--no-cpu-baseline', '--no-traffic',
+        '--model', args.model, '--dtype', args.dtype, '--batch',
+        str(args.batch), '--seconds', str(args.seconds)]
+    env = dict(os.environ, TMPDIR='/tmp')
+    sums = {}
+    with tempfile.TemporaryDirectory(dir='/tmp') as scratch:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = Path(scratch) / counter
+            try:
+                done = subprocess.run(
+                    [tool, '--output-format', 'csv', '--pmc', counter,
+                     '--kernel-trace', '-d', str(out), '-o', counter, '--'] +
+                    command, cwd='/tmp', env=env, capture_output=True,
+                    text=True, timeout=timeout)
+            except subprocess.TimeoutExpired:
+                return None, f'rocprofv3 {counter} pass timed out'
+            files = list(out.rglob('*counter_collection.csv'))
+            if done.returncode != 0 or not files:
+                return None, f'rocprofv3 {counter} pass failed'
+            values, counts = {}, {}
+            for file in files:
+                for row in csv.DictReader(open(file)):
+                    if row.get('Counter_Name') != counter:
+                        continue
+                    label = kernel_label(row['Kernel_Name'])
+                    if label is None:
+                        continue
+                    values[label] = values.get(label, 0.) + \
+                        float(row['Counter_Value'])
+                    counts[label] = counts.get(label, 0) + 1
+            # (the warm-up step and the profiled step: average per dispatch)
+            sums[counter] = {k: values[k] / counts[k] for k in values}
+    table = {
+        label: (sums['FETCH_SIZE'][label] * 2 +
+                sums['WRITE_SIZE'].get(label, 0.)) * 1024
+        for label in sums['FETCH_SIZE']}
+    return table, ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                   '(separate passes over one step of the same command), '
+                   '(FETCH_SIZE x 2 + WRITE_SIZE) x 1024 per dispatch')
 
 
 def parse_profile(text):
@@ -589,9 +676,20 @@ def main():
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             traffic, measured_step_bytes, covered_ms = None, None, 0.
             operand = operand_type_of(label, args.dtype)
+            table, traffic_source = None, None
+            if not args.no_traffic and world == 1:
+                table, traffic_source = measure_traffic(args)
+                if table is not None:
+                    table = {f'{k}:{args.dtype}': v for k, v in table.items()}
             traffic_file = ROOT / 'profiles' / 'traffic.json'
-            if traffic_file.exists() and args.batch == 32 and frames == 861:
+            if table is None and traffic_file.exists() and \
+                    args.batch == 32 and frames == 861:
                 table = json.loads(traffic_file.read_text())
+                traffic_source = (
+                    'profiles/traffic.json: rocprofv3 PMC of this build '
+                    '(FETCH_SIZE x 2 + WRITE_SIZE, separate passes), not '
+                    f're-measured in this run ({traffic_source or "--no-traffic"})')
+            if table is not None:
                 traffic = table.get(f'{label}:{args.dtype}')
                 measured_step_bytes = 0.
                 for key, entry in profile.items():
@@ -613,10 +711,7 @@ def main():
                 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_TFLOPS[operand],
                 'traffic': traffic,
-                'traffic_source': (
-                    'profiles/traffic.json: rocprofv3 PMC of this build '
-                    '(FETCH_SIZE x 2 + WRITE_SIZE, separate passes), not '
-                    're-measured in this run' if traffic else None),
+                'traffic_source': traffic_source if traffic else None,
                 'sustained_peak': SUSTAINED_TFLOPS.get(operand),
                 'frac_of_sustained_peak': (
                     achieved / SUSTAINED_TFLOPS[operand]

@@ -102,7 +102,8 @@ def test_bench_self_launches_two_ranks(device):
                         'MASTER_PORT', 'LOCAL_WORLD_SIZE')}
     done = subprocess.run(
         [sys.executable, str(root / 'bench.py'), '--gpus', '2', '--steps', '2',
-         '--warmup', '1', '--batch', '4', '--seconds', '2', '--sustain', '0'],
+         '--warmup', '1', '--batch', '4', '--seconds', '2', '--sustain', '0',
+         '--no-cpu-baseline'],
         capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert done.returncode == 0, done.stderr[-2000:]
     lines = [l for l in done.stdout.splitlines() if l.startswith('{')]
