@@ -133,8 +133,11 @@ int pm_hifigan_forward_ragged(pm_hifigan_t h, const float* features,
  * kernel the forward launches; no reference counterpart - the reference only
  * has wall-clock torchutil timers, synthesize/core.py:222,250). collect()
  * synchronises and folds the recorded pairs into per-label totals; report()
- * returns "label launches total_ms algorithmic_flops algorithmic_bytes" lines. */
+ * returns "label launches total_ms algorithmic_flops algorithmic_bytes" lines.
+ * profile_only(label) restricts the events to that label's launches (NULL or
+ * "": every launch), so that a timed region pays for two events per step.  */
 int pm_hifigan_profile_enable(pm_hifigan_t h, int enable);
+int pm_hifigan_profile_only(pm_hifigan_t h, const char* label);
 int pm_hifigan_profile_collect(pm_hifigan_t h);
 int pm_hifigan_profile_reset(pm_hifigan_t h);
 const char* pm_hifigan_profile_report(pm_hifigan_t h);

@@ -54,6 +54,7 @@ SIGNATURES = {
     'pm_hifigan_forward_cl': (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _S, _P]),
     'pm_hifigan_forward_ragged': (_I, [_P, _P, _I, _P, _I, _P, _P, _I, _I, _P, _S, _P]),
     'pm_hifigan_profile_enable': (_I, [_P, _I]),
+    'pm_hifigan_profile_only': (_I, [_P, ctypes.c_char_p]),
     'pm_hifigan_profile_collect': (_I, [_P]),
     'pm_hifigan_profile_reset': (_I, [_P]),
     'pm_hifigan_profile_report': (ctypes.c_char_p, [_P]),

@@ -293,6 +293,7 @@ struct pm_hifigan_s {
     bool finalized = false;
     // ---- optional per-launch timing with HIP events (bench.py roofline) ----
     bool profile = false;
+    std::string profile_only;            // bracket this label's launches only
     std::vector<hipEvent_t> events;      // pool, grown on demand
     size_t events_used = 0;
     struct Mark { std::string label; double flops, bytes; size_t e0, e1; };
@@ -317,9 +318,11 @@ static int prof_event(pm_hifigan_t h, hipStream_t s, size_t* index) {
 #define PROF(h, s, label_, flops_, bytes_, body)                             \
     do {                                                                     \
         size_t e0_ = 0, e1_ = 0;                                             \
-        if ((h)->profile) { int r_ = prof_event(h, s, &e0_); if (r_) return r_; } \
+        const bool on_ = (h)->profile &&                                     \
+            ((h)->profile_only.empty() || (h)->profile_only == (label_));    \
+        if (on_) { int r_ = prof_event(h, s, &e0_); if (r_) return r_; }     \
         body;                                                                \
-        if ((h)->profile) {                                                  \
+        if (on_) {                                                           \
             int r_ = prof_event(h, s, &e1_); if (r_) return r_;              \
             (h)->marks.push_back({label_, (double)(flops_), (double)(bytes_), e0_, e1_}); \
         }                                                                    \
@@ -792,12 +795,14 @@ static int forward_impl(
             char label[64];
             snprintf(label, sizeof(label), "mrf_c%d", st.cout);
             hipError_t e = hipSuccess;
+            const size_t marks_before = h->marks.size();
             PROF(h, s, label, flops, (double)B * L * st.cout * 4 * 2, {
                 e = launch_mrf(st.dtype, st.cout_pad, blocks, s);
                 if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
             });
             mrf_done = e == hipSuccess;
-            if (!mrf_done && h->profile) h->marks.pop_back();
+            if (!mrf_done && h->marks.size() > marks_before)
+                h->marks.pop_back();
         }
         for (int j = 0; !mrf_done && j < h->cfg.num_resblocks; ++j) {
             const int K = h->cfg.resblock_kernel_sizes[j];
@@ -838,13 +843,15 @@ static int forward_impl(
                 char label[64];
                 snprintf(label, sizeof(label), "block_c%d_k%d", st.cout, K);
                 hipError_t e = hipSuccess;
+                const size_t marks_before = h->marks.size();
                 PROF(h, s, label, flops,
                      (double)B * L * st.cout * 4 * (a.mode == 2 ? 3 : 2), {
                     e = launch_block3(st.dtype, st.cout_pad, K, a, s);
                     if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
                 });
                 fused = e == hipSuccess;
-                if (!fused && h->profile) h->marks.pop_back();
+                if (!fused && h->marks.size() > marks_before)
+                    h->marks.pop_back();
                 if (fused && act16_done) x16 = buf[ai];
             }
             if (fused) continue;
@@ -902,6 +909,15 @@ static int forward_impl(
 extern "C" int pm_hifigan_profile_enable(pm_hifigan_t h, int enable) {
     if (!h) return fail(PM_EINVAL, "null handle");
     h->profile = enable != 0;
+    return PM_OK;
+}
+
+// Restrict the event pairs to the launches reported under `label` (null or
+// "": all of them): a timed region then carries two events per step instead
+// of two per launch.
+extern "C" int pm_hifigan_profile_only(pm_hifigan_t h, const char* label) {
+    if (!h) return fail(PM_EINVAL, "null handle");
+    h->profile_only = label ? label : "";
     return PM_OK;
 }
 
