@@ -219,47 +219,253 @@ def from_files_to_files_batched(
     loudness_ratio: float = 1.,
     checkpoint: Optional[Union[str, os.PathLike]] = None,
     gpu: Optional[int] = None,
-    batch_size: int = 32
+    batch_size: int = 32,
+    num_workers: Optional[int] = None
 ) -> None:
     """`from_files_to_files` with the files synthesised `batch_size` at a
     time (sorted by length, zero-padded, ragged-exact) instead of the
     reference's one-utterance loop (synthesize/core.py:158-201). Same files,
-    same audio as the sequential path. SURVEY.md 8(f) item 2."""
+    same audio as the sequential path. SURVEY.md 8(f) item 2.
+
+    `num_workers` CPU processes (default: NUM_WORKERS, the size of the pools
+    the reference forks for its file-level preprocessing, defaults.py:387; 0:
+    everything in this process) unpickle the feature files, pad the batches
+    and write the wav files while the GPU synthesises: the serial loop spends
+    three quarters of its time in `torch.load` and the wav writer. The pool is
+    started on first use and kept (`shutdown_workers()` ends it); small jobs
+    (fewer than 4 batches) do not start one and run in this process. As with
+    any `spawn` pool - the reference's included - a calling SCRIPT needs its
+    `if __name__ == '__main__':` guard."""
     device = _device(gpu)
+    count = len(pitch_files)
     if speakers is None:
-        speakers = [0] * len(pitch_files)
+        speakers = [0] * count
+    if num_workers is None:
+        num_workers = promonet_amd.NUM_WORKERS
+    num_workers = min(int(num_workers), os.cpu_count() or 1)
+    files = (loudness_files, pitch_files, periodicity_files, ppg_files)
+    if num_workers < 1 or (count < 4 * batch_size and
+                           getattr(_worker_pool, 'pool', None) is None):
+        lengths = _load_lengths(pitch_files)
+        # (longest first: the engine's workspace is sized once, not per batch)
+        order = sorted(range(count), key=lambda index: (-lengths[index], index))
+        for start in range(0, count, batch_size):
+            group = order[start:start + batch_size]
+            batch = _load_group([[f[i] for i in group] for f in files])
+            audio = _synthesize_group(
+                batch, [speakers[i] for i in group], spectral_balance_ratio,
+                loudness_ratio, checkpoint, gpu).cpu()
+            _write_group(
+                audio, 0, [output_files[i] for i in group], batch[0])
+        return
+
+    import collections
+    pool = _worker_pool(num_workers)
+    chunk = -(-count // num_workers)
+    with timer.context('files/lengths'):
+        lengths = sum(pool.map(
+            _load_lengths,
+            [pitch_files[i:i + chunk] for i in range(0, count, chunk)]), [])
+    # (longest first: the engine's workspace and every buffer of the caching
+    # allocator are sized by the first batch instead of growing 32 times)
+    order = sorted(range(count), key=lambda index: (-lengths[index], index))
+    groups = [order[i:i + batch_size] for i in range(0, count, batch_size)]
+    depth = 2 * num_workers           # batches in flight on either side
+    loads = collections.deque()
+    # Audio leaves through a ring of host buffers in SHARED memory, allocated
+    # once: a tensor pickled to a worker travels as a handle, whereas a fresh
+    # 28 MB tensor per batch costs its page faults again in every process
+    # (measured: 36 ms per batch, more than its synthesis).
+    hop = promonet_amd.HOPSIZE
+    ring = getattr(_worker_pool, 'ring', None)
+    if ring is None or ring[0].shape[0] < batch_size or \
+            ring[0].shape[-1] < max(lengths) * hop:
+        # (kept with the pool: 4 x 28 MB of fresh shared pages are 0.15 s)
+        with timer.context('files/ring'):
+            ring = _worker_pool.ring = [
+                torch.empty(batch_size, 1, max(lengths) * hop).share_memory_()
+                for _ in range(4)]
+            # page-lock the shared pages: the D2H copy of a batch (28 MB) is
+            # then a DMA at link speed instead of a staged pageable copy
+            try:
+                runtime = torch.cuda.cudart()
+                for buffer in ring:
+                    runtime.cudaHostRegister(
+                        buffer.data_ptr(), buffer.numel() * 4, 0)
+            except Exception:
+                pass
+    busy = [[] for _ in ring]         # write tasks still reading a slot
+    copy_stream = torch.cuda.Stream(device)
+    submitted, previous = 0, None
+
+    def flush(item, slot):
+        """D2H of a finished batch on the side stream into ring slot `slot`,
+        then off to the writer processes, a few files per task."""
+        audio, done, names, frames = item
+        with timer.context('files/wait for writers'):
+            for task in busy[slot]:
+                task.get()
+        with timer.context('files/audio to host'):
+            copy_stream.wait_event(done)
+            with torch.cuda.stream(copy_stream):
+                ring[slot][:audio.shape[0], :, :audio.shape[-1]].copy_(
+                    audio, non_blocking=True)
+            copy_stream.synchronize()
+        busy[slot] = [
+            pool.apply_async(_write_group, (
+                ring[slot], first, names[first:first + 8],
+                frames[first:first + 8]))
+            for first in range(0, len(names), 8)]
+
+    upload_stream = torch.cuda.Stream(device)
+
+    def refill():
+        nonlocal submitted
+        while submitted < len(groups) and len(loads) < depth:
+            loads.append(pool.apply_async(_load_group, (
+                [[f[i] for i in groups[submitted]] for f in files],)))
+            submitted += 1
+
+    def upload(number):
+        """Batch `number` from its loader to the device on a side stream: a
+        copy out of pageable memory is stream-ordered AND blocks the host, so
+        on the compute stream it would wait for the forward in front of it."""
+        refill()
+        with timer.context('files/wait for loaders'):
+            batch = loads.popleft().get()
+        ids = [speakers[i] for i in groups[number]]
+        _check_speakers(ids)
+        with torch.cuda.stream(upload_stream):
+            tensors = [t.to(device, non_blocking=True) for t in batch[1:]]
+            tensors.append(torch.tensor(ids, dtype=torch.long).to(
+                device, non_blocking=True))
+            tensors.append(torch.tensor(batch[0], dtype=torch.int32).to(
+                device, non_blocking=True))
+            ready = torch.cuda.Event()
+            ready.record(upload_stream)
+        return batch[0], tensors, ready
+
+    staged = upload(0)
+    for number, group in enumerate(groups):
+        frames, tensors, ready = staged
+        compute = torch.cuda.current_stream(device)
+        compute.wait_event(ready)
+        for tensor in tensors:
+            tensor.record_stream(compute)
+        audio = _synthesize_group(
+            (tensors[5], *tensors[:4]), tensors[4], spectral_balance_ratio,
+            loudness_ratio, checkpoint, gpu)
+        done = torch.cuda.Event()
+        done.record(compute)
+        # (the next batch arrives and the previous one leaves the device while
+        # this one computes)
+        if number + 1 < len(groups):
+            staged = upload(number + 1)
+        if previous is not None:
+            flush(previous, (number - 1) % len(ring))
+        previous = (audio, done, [output_files[i] for i in group], frames)
+    if previous is not None:
+        flush(previous, (len(groups) - 1) % len(ring))
+    with timer.context('files/wait for writers'):
+        for tasks in busy:
+            for task in tasks:
+                task.get()
+
+
+def _worker_pool(num_workers):
+    """The IO processes, started once and kept (ten `spawn`ed interpreters
+    importing torch take seconds - more than a thousand files' worth of
+    synthesis): cached on the function like the model (`generate.model`),
+    replaced when another size is asked for, ended by `shutdown_workers()` or
+    at interpreter exit."""
+    cached = getattr(_worker_pool, 'pool', None)
+    if cached is not None and cached[0] == num_workers:
+        return cached[1]
+    shutdown_workers()
+    import atexit
+    import torch.multiprocessing as mp
+    # ('spawn': the children never touch the GPU, but a fork of a process that
+    # has initialised HIP inherits its runtime threads' locks)
+    pool = mp.get_context('spawn').Pool(num_workers, initializer=_worker_init)
+    _worker_pool.pool = (num_workers, pool)
+    if not getattr(_worker_pool, 'registered', False):
+        atexit.register(shutdown_workers)
+        _worker_pool.registered = True
+    return pool
+
+
+def _worker_init():
+    # (unpickling and padding are single-threaded work: ten processes with
+    # one intra-op thread pool per host core each would only fight)
+    torch.set_num_threads(1)
+
+
+def shutdown_workers():
+    """End the IO worker processes of `from_files_to_files_batched`."""
+    cached = getattr(_worker_pool, 'pool', None)
+    if cached is not None:
+        cached[1].terminate()
+        cached[1].join()
+        _worker_pool.pool = None
+        for buffer in getattr(_worker_pool, 'ring', None) or []:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(buffer.data_ptr())
+            except Exception:
+                pass
+        _worker_pool.ring = None
+
+
+def _load_lengths(pitch_files):
+    """Frames of every utterance (worker side)."""
+    return [int(torch.load(file).shape[-1]) for file in pitch_files]
+
+
+def _load_group(files):
+    """One zero-padded batch from the four feature files of its utterances
+    (worker side: CPU only). Returns (frames per utterance, loudness
+    (B, bands, T), pitch (B, T), periodicity (B, T), ppg (B, 40, T))."""
+    loudness_files, pitch_files, periodicity_files, ppg_files = files
     items = []
     for index in range(len(pitch_files)):
         pitch = torch.load(pitch_files[index])
+        frames = int(pitch.shape[-1])
         items.append((
-            pitch.shape[-1], index, torch.load(loudness_files[index]), pitch,
-            torch.load(periodicity_files[index]),
-            promonet_amd.load.ppg(ppg_files[index], pitch.shape[-1])))
-    items.sort(key=lambda item: item[0])
-    for start in range(0, len(items), batch_size):
-        group = items[start:start + batch_size]
-        frames = max(item[0] for item in group)
+            frames, torch.load(loudness_files[index]).reshape(-1, frames),
+            pitch.reshape(frames),
+            torch.load(periodicity_files[index]).reshape(frames),
+            promonet_amd.load.ppg(ppg_files[index], frames).reshape(
+                -1, frames)))
+    longest = max(item[0] for item in items)
 
-        def padded(tensors):
-            out = torch.zeros(
-                (len(tensors),) + tuple(tensors[0].shape[:-1]) + (frames,))
-            for row, tensor in zip(out, tensors):
-                row[..., :tensor.shape[-1]] = tensor
-            return out.to(device)
+    def padded(column):
+        first = items[0][column]
+        out = torch.zeros(
+            (len(items),) + tuple(first.shape[:-1]) + (longest,),
+            dtype=torch.float32)
+        for row, item in zip(out, items):
+            row[..., :item[0]] = item[column]
+        return out
+    return ([item[0] for item in items], padded(1), padded(2), padded(3),
+            padded(4))
 
-        audio = from_features_batched(
-            padded([item[2].reshape(-1, item[0]) for item in group]),
-            padded([item[3].reshape(item[0]) for item in group]),
-            padded([item[4].reshape(item[0]) for item in group]),
-            padded([item[5].reshape(-1, item[0]) for item in group]),
-            [speakers[item[1]] for item in group], spectral_balance_ratio,
-            loudness_ratio, checkpoint, gpu,
-            lengths=[item[0] for item in group]).cpu()
-        for row, item in zip(audio, group):
-            output_file = Path(output_files[item[1]])
-            output_file.parent.mkdir(exist_ok=True, parents=True)
-            save_audio(
-                output_file, row[:, :item[0] * promonet_amd.HOPSIZE])
+
+def _synthesize_group(
+    batch, speakers, spectral_balance_ratio, loudness_ratio, checkpoint, gpu
+):
+    frames, loudness, pitch, periodicity, ppg = batch
+    return from_features_batched(
+        loudness, pitch, periodicity, ppg, speakers, spectral_balance_ratio,
+        loudness_ratio, checkpoint, gpu, lengths=frames)
+
+
+def _write_group(audio, first, output_files, frames):
+    """Rows first ... of the (B, 1, samples) host audio -> one wav per
+    utterance, cut to its length (worker side)."""
+    for offset, (file, count) in enumerate(zip(output_files, frames)):
+        file = Path(file)
+        file.parent.mkdir(exist_ok=True, parents=True)
+        save_audio(
+            file, audio[first + offset, :, :count * promonet_amd.HOPSIZE])
 
 
 ###############################################################################

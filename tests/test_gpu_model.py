@@ -741,6 +741,46 @@ def test_files_to_files_batched(device, default_state, tmp_path):
         assert (audio_a == audio_b).all()
 
 
+def test_files_to_files_batched_worker_pipeline(device, default_state, tmp_path):
+    """The worker-process IO pipeline of the batched file path (feature files
+    unpickled and padded, wav files written by CPU processes while the GPU
+    synthesises; the previous batch's audio leaves the device on a side
+    stream): same bytes in every output file as the in-process loop, for a job
+    large enough to take the pool (9 batches of 4, uneven last batch)."""
+    import promonet_amd
+    import scipy.io.wavfile
+    model = make_model(default_state, 'bf16', device)
+    promonet_amd.synthesize.set_model(model, device)
+    gen = torch.Generator().manual_seed(11)
+    lengths = [int(torch.randint(3, 60, (1,), generator=gen)) for _ in range(34)]
+    files = {key: [] for key in (
+        'loudness', 'pitch', 'periodicity', 'ppg', 'pool', 'serial')}
+    for index, length in enumerate(lengths):
+        inputs = oracle.synthetic_inputs(1, length, seed=400 + index)
+        torch.save(inputs[0][0], tmp_path / f'{index}-loudness.pt')
+        torch.save(inputs[1], tmp_path / f'{index}-pitch.pt')
+        torch.save(inputs[2], tmp_path / f'{index}-periodicity.pt')
+        torch.save(inputs[3][0], tmp_path / f'{index}-ppg.pt')
+        for key in ('loudness', 'pitch', 'periodicity', 'ppg'):
+            files[key].append(tmp_path / f'{index}-{key}.pt')
+        files['pool'].append(tmp_path / 'pool' / f'{index}.wav')
+        files['serial'].append(tmp_path / 'serial' / f'{index}.wav')
+    args = [files[k] for k in ('loudness', 'pitch', 'periodicity', 'ppg')]
+    speakers = [index % 7 for index in range(len(lengths))]
+    promonet_amd.synthesize.from_files_to_files_batched(
+        *args, files['pool'], speakers=speakers, gpu=0, batch_size=4,
+        num_workers=3)
+    promonet_amd.synthesize.from_files_to_files_batched(
+        *args, files['serial'], speakers=speakers, gpu=0, batch_size=4,
+        num_workers=0)
+    for a, b, length in zip(files['pool'], files['serial'], lengths):
+        rate_a, audio_a = scipy.io.wavfile.read(a)
+        rate_b, audio_b = scipy.io.wavfile.read(b)
+        assert rate_a == rate_b == 22050
+        assert audio_a.shape == audio_b.shape == (length * 256,)
+        assert (audio_a == audio_b).all()
+
+
 def test_packed_interface(device, golden_default, default_state):
     """pack_features / unpack_features / packed_inference (the nn~ buffer
     contract, generator.py:255-422) against the real reference's output."""
