@@ -260,6 +260,8 @@ def operand_type_of(label, dtype):
     `mrf_c32` ...) ran with when `dtype` names one type per stage."""
     import re
     parts = dtype.split('+')
+    if parts == ['checkpoint']:
+        parts = ['f16', 'f16', 'f16', 'f16x3']
     if len(parts) == 1:
         return parts[0]
     match = re.search(r'_c(\d+)', label)
@@ -589,7 +591,8 @@ def main():
                 f'{args.dtype} operands at the 1e-4 max-abs gate on RANDOM-INIT '
                 'weights (audio peak 0.017: tests/test_gpu_model.py::'
                 'test_full_size_every_sample); at trained-checkpoint scale see '
-                'DESIGN.md section 3 - the library default is f16'),
+                'DESIGN.md section 3 - the library default is the split-f16 '
+                "'checkpoint' mode (--dtype checkpoint)"),
             'data': 'synthetic',
             'config': {
                 'workload': workload,
@@ -763,7 +766,7 @@ def main():
             result['whole_path'] = {
                 'tflops': per_gpu * FLOP_PER_SAMPLE / 1e12,
                 'frac_of_mfma_peak': per_gpu * FLOP_PER_SAMPLE / 1e12 /
-                                     PEAK_TFLOPS[args.dtype.split('+')[0]],
+                                     PEAK_TFLOPS[operand_type_of('input_conv', args.dtype)],
                 # HBM bytes the kernels really moved per step (rocprofv3 PMC,
                 # FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic.json) over
                 # this run's step time: the ACHIEVED HBM rate

@@ -136,9 +136,14 @@ class HiFiGAN(torch.nn.Module):
                 raise ValueError('ragged dilation lists are not supported')
             for n, d in enumerate(self.res_dilations[j]):
                 config.resblock_dilations[j][n] = d
-        # 'bf16' / 'f16' / 'fp32', or one operand type per upsampling stage
-        # joined by '+' ('bf16+bf16+f16+f16': the input conv takes the first)
+        # 'checkpoint' / 'bf16' / 'f16' / 'fp32' / 'f16x3', or one operand type
+        # per upsampling stage joined by '+' ('bf16+bf16+f16+f16': the input
+        # conv takes the first)
         per_stage = str(self.compute_dtype).split('+')
+        if per_stage == ['checkpoint']:
+            # the trained-checkpoint mode (config.py): f16 operands, split
+            # into hi + lo in the last upsampling stage
+            per_stage = ['f16'] * (len(self.rates) - 1) + ['f16x3']
         if len(per_stage) not in (1, len(self.rates)):
             raise ValueError(
                 f'COMPUTE_DTYPE {self.compute_dtype!r}: one operand type, or '

@@ -5,6 +5,8 @@ audio peaks near 1. Here the output conv is rescaled so that the audio peaks at
 ~0.5 (same arithmetic everywhere else, so the relative error of the trunk is
 unchanged) and every operand-type choice - including per-stage mixes - is
 compared, on every sample, with the fp32 CPU oracle on the same weights.
+Round 4: a second trained-scale column at peak 0.99 and the split-f16 modes
+('checkpoint' = f16, f16x3 in the last stage; 'f16x3' everywhere).
 
 usage: python scripts/precision_sweep.py [batch] [frames]"""
 import json
@@ -23,8 +25,9 @@ import restatement as oracle  # noqa: E402
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 861
 device = torch.device('cuda:0')
-VARIANTS = ['fp32', 'f16', 'bf16', 'bf16+bf16+f16+f16', 'bf16+f16+f16+f16',
-            'bf16+bf16+bf16+f16', 'f16+f16+bf16+bf16']
+VARIANTS = ['fp32', 'checkpoint', 'f16x3', 'f16', 'bf16', 'bf16+bf16+f16+f16',
+            'bf16+f16+f16+f16', 'bf16+bf16+bf16+f16', 'bf16+bf16+bf16+f16x3',
+            'f16+f16+bf16+bf16']
 
 
 def reference(inputs, state):
@@ -65,13 +68,16 @@ state = oracle.random_state(seed=golden['seed'])
 state['pitch_distribution'] = golden['pitch_distribution'].clone()
 inputs = oracle.synthetic_inputs(batch, frames, seed=1234)
 result = {'batch': batch, 'frames': frames, 'cases': {}}
-for label in ('random_init', 'trained_scale'):
-    if label == 'trained_scale':
-        # audio = tanh(conv(...)): scale the output conv so that it peaks ~0.5
+base_state = state
+for label, peak_target in (
+        ('random_init', None), ('trained_scale', .5), ('trained_scale_0.99', .99)):
+    if peak_target is not None:
+        # audio = tanh(conv(...)): scale the output conv so that it peaks at
+        # `peak_target` (0.99: the pre-tanh amplitude is 4.8x that of 0.5)
         peak = result['cases']['random_init']['reference_abs_max']
-        factor = float(torch.atanh(torch.tensor(0.5))) / float(
+        factor = float(torch.atanh(torch.tensor(peak_target))) / float(
             torch.atanh(torch.tensor(peak)))
-        state = dict(state)
+        state = dict(base_state)
         key = [k for k in state if k.endswith('model.5.weight')][0]
         state[key] = state[key] * factor
         result['cases'][label] = {'output_conv_scale': factor}

@@ -388,15 +388,20 @@ def test_trained_checkpoint_mode_holds_the_gate_near_full_scale(
         want = oracle.generator_forward(*inputs, state)
     scale = want.abs().max().item()
     assert .98 < scale < 1.
-    errors = {}
-    for dtype in ('f16+f16+f16+f16x3', 'f16', 'fp32'):
+    import promonet_amd
+    assert promonet_amd.config.DEFAULT_COMPUTE_DTYPE == 'checkpoint'
+    errors, outputs = {}, {}
+    for dtype in ('f16+f16+f16+f16x3', 'checkpoint', 'f16', 'fp32'):
         model = make_model(state, dtype, device)
         with torch.inference_mode():
             got = model(*on(device, inputs), None)
+        outputs[dtype] = got
         errors[dtype] = max_abs(got, want)
         print(f'trained scale (peak {scale:.3f}) {dtype}: max-abs '
               f'{errors[dtype]:.3e}')
         del model
+    # ('checkpoint', the library default, is that mode for any stage count)
+    assert torch.equal(outputs['checkpoint'], outputs['f16+f16+f16+f16x3'])
     check(errors['f16+f16+f16+f16x3'], 1e-4, 'trained_scale_peak0.99:f16x3')
     check(errors['fp32'], 3e-5, 'trained_scale_peak0.99:fp32')
     assert errors['f16'] > 1e-4       # (why the mode exists)
