@@ -1559,6 +1559,17 @@ static int fft_launch(FftArgs& a, hipStream_t s,
         HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
         hipLaunchKernelGGL(kern, dim3((a.T + 31) / 32, a.B), dim3(512), smem,
                            s, a);
+    } else if constexpr (EPI == 1 || EPI == 4) {
+        // 16 frames by EIGHT waves of two frames: two 512-thread workgroups
+        // per CU at 128 registers = four waves per SIMD to cover the eight
+        // wave-private LDS hand-overs of a frame (profiles/r04/stft_pmc.txt:
+        // magnitude 53.6 -> 50.4 us, log-mel 62.7 -> 50.6 us; the dB epilogues
+        // of the loudness passes want 166 registers and lose 50 % this way)
+        auto kern = pm_stft_fft_kernel<EPI, 8, 2>;
+        constexpr int smem = pm_fft_smem_bytes<EPI, 8, 2>();
+        HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
+        hipLaunchKernelGGL(kern, dim3((a.T + 15) / 16, a.B), dim3(512), smem,
+                           s, a);
     } else {
         auto kern = pm_stft_fft_kernel<EPI, 4, 4>;
         constexpr int smem = pm_fft_smem_bytes<EPI, 4, 4>();
