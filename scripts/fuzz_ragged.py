@@ -30,7 +30,7 @@ from promonet_amd import _lib  # noqa: E402
 device = torch.device('cuda:0')
 state = oracle.random_state(seed=0)
 models = {}
-for dtype in ('bf16', 'f16', 'fp32'):
+for dtype in ('bf16', 'f16', 'fp32', 'checkpoint'):
     promonet_amd.configure(COMPUTE_DTYPE=dtype)
     model = promonet_amd.model.Generator()
     model.load_state_dict(state)
