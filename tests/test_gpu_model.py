@@ -327,6 +327,26 @@ def test_full_size_every_sample(device, default_state):
         check(rms, {'bf16': 1.5e-5, 'f16': 1.8e-6}[dtype],
               f'full_size_rms:{dtype}')
         del model
+    # The same 7 053 312 samples at a TRAINED checkpoint's output scale, in the
+    # library's default operand mode: the output conv rescaled so that the
+    # audio peaks at 0.99 (section 3 of DESIGN.md). Its reference needs no
+    # second CPU pass: the conv is linear in its weights, so the scaled model's
+    # audio is tanh(f atanh(audio)) of the oracle's (evaluated in float64).
+    import math
+    peak = want.abs().max().item()
+    factor = math.atanh(.99) / math.atanh(peak)
+    scaled = dict(default_state)
+    scaled['model.model.5.weight'] = scaled['model.model.5.weight'] * factor
+    want_scaled = torch.tanh(factor * torch.atanh(want.double()))
+    model = make_model(scaled, 'checkpoint', device)
+    with torch.inference_mode():
+        got = model(*on(device, inputs), None).cpu()
+    difference = (got.double() - want_scaled).abs()
+    error = difference.max().item()
+    print(f'full size at audio peak {want_scaled.abs().max().item():.3f}, '
+          f"'checkpoint' operands: max-abs {error:.3e} rms "
+          f'{difference.pow(2).mean().sqrt().item():.3e}')
+    check(error, 1e-4, 'full_size_peak0.99:checkpoint')
 
 
 def test_precision_at_trained_scale(device, default_state):
