@@ -281,6 +281,7 @@ def from_files_to_files_batched(
     if ring is None or ring[0].shape[0] < batch_size or \
             ring[0].shape[-1] < max(lengths) * hop:
         # (kept with the pool: 4 x 28 MB of fresh shared pages are 0.15 s)
+        _release_ring()
         with timer.context('files/ring'):
             ring = _worker_pool.ring = [
                 torch.empty(batch_size, 1, max(lengths) * hop).share_memory_()
@@ -407,12 +408,17 @@ def shutdown_workers():
         cached[1].terminate()
         cached[1].join()
         _worker_pool.pool = None
-        for buffer in getattr(_worker_pool, 'ring', None) or []:
-            try:
-                torch.cuda.cudart().cudaHostUnregister(buffer.data_ptr())
-            except Exception:
-                pass
-        _worker_pool.ring = None
+    _release_ring()
+
+
+def _release_ring():
+    """Undo the page-locking of the shared audio ring before it is dropped."""
+    for buffer in getattr(_worker_pool, 'ring', None) or []:
+        try:
+            torch.cuda.cudart().cudaHostUnregister(buffer.data_ptr())
+        except Exception:
+            pass
+    _worker_pool.ring = None
 
 
 def _load_lengths(pitch_files):
