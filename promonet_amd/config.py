@@ -77,7 +77,7 @@ FARGAN_SUBFRAMES = 4
 # the random-init output scale (audio peak 0.017: what BASELINE.json's 1e-4
 # gate is stated on) | with the output conv rescaled so that the audio peaks at
 # 0.5 | at 0.99, a trained checkpoint's scale, and the batch-32 x 10 s step:
-#   'checkpoint'      3.0e-7 | 1.2e-5 | 4.9e-5   23.8 ms  (DEFAULT) f16, the last
+#   'checkpoint'      3.0e-7 | 1.2e-5 | 4.9e-5   22.2 ms  (DEFAULT) f16, the last
 #                     upsampling stage with SPLIT f16 operands ('f16x3': hi + lo,
 #                     three MFMAs per step, ~21 bits per factor): the mode that
 #                     holds 1e-4 at a real checkpoint's output scale. Spelled

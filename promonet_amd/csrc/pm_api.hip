@@ -771,7 +771,13 @@ static int forward_impl(
         const int si = xi;   // stage input is dead after the upsampler
         // whole MRF (Blocks k = 3, 7, 11) in one launch: U -> S
         bool mrf_done = false;
-        if (fusion_level() >= 2 && h->cfg.num_resblocks == 3 &&
+        // (split-f16 operands on a batch long enough for the skewed walk: Block
+        // by Block - three launches that recompute nothing beat the fused
+        // whole-MRF launch and its 23 % halo there, pm_launch.h)
+        const bool x3_skew = st.dtype == PM_F16X3 && st.cout_pad == 32 &&
+            p.scratch && pm_device_cus() > 0 &&
+            (L / 512) / std::max(1, pm_device_cus() / B) >= 4;
+        if (fusion_level() >= 2 && !x3_skew && h->cfg.num_resblocks == 3 &&
             h->cfg.num_dilations <= 3 && st.cout_pad <= 64 &&
             h->cfg.resblock_kernel_sizes[0] == 3 &&
             h->cfg.resblock_kernel_sizes[1] == 7 &&

@@ -1818,13 +1818,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
     constexpr int AL = GE::AL;
     constexpr int S = GE::S;
     constexpr int QS = S / 16;
-    constexpr int G = (ET::ESZ == 4) ? 2 : KC;
+    constexpr int G = (ET::ESZ == 4) ? (ET::ID == 3 ? 1 : 2) : KC;
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;
     constexpr int W_MT_STRIDE = W_BIAS + 64;
     constexpr int AUX = 16;        // sc1: served by the L2, never by this CU's L1
     static_assert(NTW >= 2, "the trunk shift needs two tiles per wave");
-    static_assert(ET::ESZ == 2, "the exchange slot is a wave's 64 B x 64 rows of t");
+    // (the exchange slot is 64 B x 64 rows of the receiving wave's part of t: a
+    // row of its MTW x 32 channels is 64 B with 16-bit operands, 128 B with the
+    // 4-byte layouts)
+    static_assert(ET::ESZ == 2 || ET::ID == 3, "16-bit or split-f16 operands");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* abuf = smem;
@@ -2012,8 +2015,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
                 const int idx = tid + it * NT;
                 const int r = idx / Q, q = idx % Q;
                 if (idx < 32 * Q)
-                    ET::store4(abuf + (AL + NC + r) * S + q * 4 * ET::ESZ,
-                               pm_lrelu4(make_float4(
+                    ET::store4_at(abuf + (AL + NC + r) * S, q * 4,
+                                  pm_lrelu4(make_float4(
                                    __uint_as_float(pre[it].x),
                                    __uint_as_float(pre[it].y),
                                    __uint_as_float(pre[it].z),

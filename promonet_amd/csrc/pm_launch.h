@@ -292,7 +292,12 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
     constexpr int smem = block3_smem_bytes<ET, C, K, WM, WN, NTW>();
     // Skewed walk (no recompute at all) for grids that fill the chip several
     // times over: needs scratch, dilations <= 5 and H2 (d + 1) <= 30
-    if constexpr (ET::ESZ == 2 && WM * WN == 8 && NTW >= 2) {
+    // (split f16, C = 32: the last stage of the 'checkpoint' operand mode is
+    // MFMA-bound at three MFMAs per step, so what the skew removes - the 23 %
+    // halo of the stand-alone whole-MRF tiling - shows: three skewed Block
+    // launches 6.07 ms against 6.99 ms fused, profiles/r04/ab_x3_skew.txt)
+    constexpr bool X3SKEW = ET::ID == 3 && C == 32;
+    if constexpr ((ET::ESZ == 2 || X3SKEW) && WM * WN == 8 && NTW >= 2) {
         typedef SkewGeom<ET, C, K, WM, WN, NTW> GE;
         static_assert(GE::SCRATCH <= PM_SKEW_WG_SCRATCH, "scratch bound");
         const int cus = pm_device_cus();
@@ -303,7 +308,7 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
         // the walked halo is small (k 3: 12 columns) its carries and the
         // hand-over cost 5 % more than the recompute they save, on the
         // 128-column tiles of C = 256 k 7 it is even with three pair launches.
-        constexpr bool WINS = (C == 128 || C == 64) && K >= 7;
+        constexpr bool WINS = ((C == 128 || C == 64) && K >= 7) || X3SKEW;
         bool fits = GE::SMEM <= 160 * 1024 && a.niter >= 1 && a.niter <= 3 &&
                     a.scratch && (cus > 0 || forced) &&
                     (pm_force().skew > 0 || (pm_force().skew == 0 && WINS));

@@ -270,11 +270,16 @@ def test_walked_whole_block(device, dtype, channels, kernel_size):
         _lib.check(_lib.lib().pm_debug_force(0, 0))
 
 
-@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+SKEW_SHAPES = [(32, 3), (32, 7), (32, 11), (64, 3), (64, 7), (64, 11),
+               (128, 3), (128, 7), (128, 11), (256, 3), (256, 7)]
+
+
+# (split f16 takes the skewed walk in the stage it exists for: the 32-channel
+# last stage of the 'checkpoint' operand mode)
 @pytest.mark.parametrize(
-    'channels,kernel_size',
-    [(64, 3), (64, 7), (64, 11), (128, 3), (128, 7), (128, 11), (256, 3),
-     (256, 7)])
+    'dtype,channels,kernel_size',
+    [(dtype, c, k) for dtype in ('f16', 'bf16', 'f16x3') for c, k in SKEW_SHAPES
+     if dtype != 'f16x3' or c == 32])
 def test_skewed_whole_block(device, dtype, channels, kernel_size):
     """The SKEWED walk of a whole Block (conv_block3_skew_kernel: iteration i
     works 32 i columns behind iteration 0, the trunk moves one tile to the
@@ -298,7 +303,8 @@ def test_skewed_whole_block(device, dtype, channels, kernel_size):
     scratch = _lib.lib().pm_walk_scratch_bytes(2)
     assert scratch > 0
     ws = torch.empty(weights + scratch, dtype=torch.uint8, device=device)
-    columns = {64: 256 if kernel_size == 3 else 512, 128: 256, 256: 128}[channels]
+    columns = {32: 512, 64: 256 if kernel_size == 3 else 512, 128: 256,
+               256: 128}[channels]
 
     def run(x_cl, out, length, mode, size):
         _lib.check(_lib.lib().pm_block_cl(
