@@ -774,7 +774,7 @@ static int forward_impl(
         // (split-f16 operands on a batch long enough for the skewed walk: Block
         // by Block - three launches that recompute nothing beat the fused
         // whole-MRF launch and its 23 % halo there, pm_launch.h)
-        const bool x3_skew = st.dtype == PM_F16X3 && st.cout_pad == 32 &&
+        const bool x3_skew = esz(st.dtype) == 4 && st.cout_pad == 32 &&
             p.scratch && pm_device_cus() > 0 &&
             (L / 512) / std::max(1, pm_device_cus() / B) >= 4;
         if (fusion_level() >= 2 && !x3_skew && h->cfg.num_resblocks == 3 &&

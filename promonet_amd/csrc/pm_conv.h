@@ -1827,7 +1827,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
     // (the exchange slot is 64 B x 64 rows of the receiving wave's part of t: a
     // row of its MTW x 32 channels is 64 B with 16-bit operands, 128 B with the
     // 4-byte layouts)
-    static_assert(ET::ESZ == 2 || ET::ID == 3, "16-bit or split-f16 operands");
+
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* abuf = smem;

@@ -296,7 +296,7 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
     // MFMA-bound at three MFMAs per step, so what the skew removes - the 23 %
     // halo of the stand-alone whole-MRF tiling - shows: three skewed Block
     // launches 6.07 ms against 6.99 ms fused, profiles/r04/ab_x3_skew.txt)
-    constexpr bool X3SKEW = ET::ID == 3 && C == 32;
+    constexpr bool X3SKEW = ET::ESZ == 4 && (C == 32 || C == 64);
     if constexpr ((ET::ESZ == 2 || X3SKEW) && WM * WN == 8 && NTW >= 2) {
         typedef SkewGeom<ET, C, K, WM, WN, NTW> GE;
         static_assert(GE::SCRATCH <= PM_SKEW_WG_SCRATCH, "scratch bound");

@@ -274,12 +274,12 @@ SKEW_SHAPES = [(32, 3), (32, 7), (32, 11), (64, 3), (64, 7), (64, 11),
                (128, 3), (128, 7), (128, 11), (256, 3), (256, 7)]
 
 
-# (split f16 takes the skewed walk in the stage it exists for: the 32-channel
-# last stage of the 'checkpoint' operand mode)
+# (the 4-byte operand layouts - exact fp32, split f16 - take the skewed walk
+# where they have whole-Block tilings: C <= 64)
 @pytest.mark.parametrize(
     'dtype,channels,kernel_size',
-    [(dtype, c, k) for dtype in ('f16', 'bf16', 'f16x3') for c, k in SKEW_SHAPES
-     if dtype != 'f16x3' or c == 32])
+    [(dtype, c, k) for dtype in ('f16', 'bf16', 'f16x3', 'fp32')
+     for c, k in SKEW_SHAPES if dtype in ('f16', 'bf16') or c <= 64])
 def test_skewed_whole_block(device, dtype, channels, kernel_size):
     """The SKEWED walk of a whole Block (conv_block3_skew_kernel: iteration i
     works 32 i columns behind iteration 0, the trunk moves one tile to the
@@ -305,6 +305,8 @@ def test_skewed_whole_block(device, dtype, channels, kernel_size):
     ws = torch.empty(weights + scratch, dtype=torch.uint8, device=device)
     columns = {32: 512, 64: 256 if kernel_size == 3 else 512, 128: 256,
                256: 128}[channels]
+    if dtype in ('fp32', 'f16x3') and channels == 64:
+        columns = 256
 
     def run(x_cl, out, length, mode, size):
         _lib.check(_lib.lib().pm_block_cl(
