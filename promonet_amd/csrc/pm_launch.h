@@ -130,8 +130,12 @@ template <> struct PairCfg<ElemF16, 64>  { enum { WM = 2, WN = 2, NTW = 2, CH = 
 template <> struct PairCfg<ElemF16, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
 template <int C> struct PairCfg<ElemBF16, C> : PairCfg<ElemF16, C> {};
 // exact fp32 operands: LDS rows are twice as wide -> 64-column tiles
-template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
-template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
+// (round 4: 128-column tiles with the conv1 -> conv2 tile overlaying the x
+// chunks instead of 64-column ones: 8 % of the columns recomputed instead of
+// 16 % at k 11 and half the weight bytes per column - config 2 22.1 -> 20.4 ms;
+// 192 columns at C = 128, where they fit: 19.7 ms - profiles/r04/ab_x3_skew.txt)
+template <> struct PairCfg<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 2, CH = 64, ALIAS = 1 }; };
+template <> struct PairCfg<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 3, CH = 64, ALIAS = 1 }; };
 template <> struct PairCfg<ElemF32, 64>  { enum { WM = 2, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
 template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 32, ALIAS = 0 }; };
 // split f16 (hi + lo, three MFMAs per step): 4 bytes per element like fp32,
@@ -147,6 +151,11 @@ template <class ET, int C> struct PairCfgNarrow : PairCfg<ET, C> {};
 // (CH must equal the wide variant's: both read the same packed weights)
 template <> struct PairCfgNarrow<ElemF16, 256> { enum { WM = 8, WN = 1, NTW = 2, CH = PairCfg<ElemF16, 256>::CH, ALIAS = 1 }; };
 template <> struct PairCfgNarrow<ElemF16, 128> { enum { WM = 4, WN = 2, NTW = 2, CH = PairCfg<ElemF16, 128>::CH, ALIAS = 0 }; };
+// (fp32: the 64-column tiles of rounds 1-3 as the latency variant)
+template <> struct PairCfgNarrow<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfgNarrow<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
+template <> struct PairCfgNarrow<ElemF16X3, 256> : PairCfgNarrow<ElemF32, 256> {};
+template <> struct PairCfgNarrow<ElemF16X3, 128> : PairCfgNarrow<ElemF32, 128> {};
 template <> struct PairCfgNarrow<ElemBF16, 256> : PairCfgNarrow<ElemF16, 256> {};
 template <> struct PairCfgNarrow<ElemBF16, 128> : PairCfgNarrow<ElemF16, 128> {};
 #define PM_NARROW_BELOW 150   // 3x the tiles must still fit ~2 rounds of 256 CUs
