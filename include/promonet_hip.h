@@ -216,6 +216,19 @@ int pm_block_cl(int dtype, const float* x_cl, float* out_cl,
                 const int* dilations, int niter, int batch, int length,
                 int channels, int kernel_size, int mode, float scale,
                 void* workspace, size_t workspace_bytes, void* stream);
+/* pm_block_cl whose result leaves as the next upsampler's MFMA operand
+ * (hifigan.py:100-106 stages lrelu(stage output) for its ConvTranspose1d):
+ * act16_cl (B, L, c_pad) 16-bit = cvt(lrelu(result)) in `act_dtype` (PM_F16 |
+ * PM_BF16) instead of the fp32 tensor; out_cl is read (mode 2) and left as it
+ * is. Only the skewed walk does it (long inputs, scratch behind the workspace,
+ * or pm_debug_skew(1)): PM_ESTATE, and the fp32 result in out_cl, otherwise. */
+int pm_block_act16_cl(int dtype, int act_dtype, const float* x_cl,
+                      float* out_cl, void* act16_cl, const float* const* w1,
+                      const float* const* b1, const float* const* w2,
+                      const float* const* b2, const int* dilations, int niter,
+                      int batch, int length, int channels, int kernel_size,
+                      int mode, float scale, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* The whole MRF ResidualBlock of one stage (hifigan.py:141-145):
  * out = (Block_3(x) + Block_7(x) + Block_11(x)) / 3 in one launch, the sum
  * held in registers (32 channels). w1/b1/w2/b2: HOST arrays of 3 * niter
@@ -246,6 +259,14 @@ int pm_conv_transpose_cl(int dtype, const float* x_cl, float* out_cl,
                          int length, int c_in, int c_out, int rate, int lrelu,
                          void* workspace, size_t workspace_bytes,
                          void* stream);
+/* pm_conv_transpose_cl on an input that already holds the operand values:
+ * x16_cl (B, L, c_in_pad) in the operand type `dtype` (PM_F16 | PM_BF16) =
+ * cvt(lrelu(x)) as pm_block_act16_cl writes it; narrow (r = 2 ...) upsamplers */
+int pm_conv_transpose_x16_cl(int dtype, const void* x16_cl, float* out_cl,
+                             const float* w, const float* bias, int batch,
+                             int length, int c_in, int c_out, int rate,
+                             void* workspace, size_t workspace_bytes,
+                             void* stream);
 /* LeakyReLU -> Conv1d(C, 1, 7, pad 3, no bias) -> tanh (hifigan.py:55-60):
  * (B, L, c_pad) channels-last -> (B, L)                                   */
 int pm_out_conv_tanh(const float* x_cl, const float* w, float* out,

@@ -64,9 +64,12 @@ SIGNATURES = {
     'pm_op_workspace_bytes': (_S, [_I, _I, _I]),
     'pm_block_iteration_cl': (_I, [_I] + [_P] * 6 + [_I] * 6 + [_F, _P, _S, _P]),
     'pm_block_cl': (_I, [_I, _P, _P] + [_P] * 5 + [_I] * 6 + [_F, _P, _S, _P]),
+    'pm_block_act16_cl': (
+        _I, [_I, _I, _P, _P, _P] + [_P] * 5 + [_I] * 6 + [_F, _P, _S, _P]),
     'pm_mrf_cl': (_I, [_I, _P, _P] + [_P] * 5 + [_I] * 4 + [_P, _S, _P]),
     'pm_input_conv_cl': (_I, [_I] + [_P] * 7 + [_I] * 6 + [_P, _S, _P]),
     'pm_conv_transpose_cl': (_I, [_I] + [_P] * 4 + [_I] * 6 + [_P, _S, _P]),
+    'pm_conv_transpose_x16_cl': (_I, [_I] + [_P] * 4 + [_I] * 5 + [_P, _S, _P]),
     'pm_out_conv_tanh': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'pm_debug_timeline': (_I, [_P]),
     'pm_debug_force': (_I, [_I, _I]),

@@ -1138,11 +1138,12 @@ extern "C" int pm_debug_timeline(void* dev_buffer) {
 #endif
 }
 
-extern "C" int pm_block_cl(
+static int block_cl_impl(
     int dtype, const float* x, float* out, const float* const* w1,
     const float* const* b1, const float* const* w2, const float* const* b2,
     const int* dilations, int niter, int B, int L, int C, int K, int mode,
-    float scale, void* ws, size_t ws_bytes, void* stream) {
+    float scale, void* ws, size_t ws_bytes, void* stream, void* act16,
+    int act_dtype) {
     if (!x || !out || !w1 || !b1 || !w2 || !b2 || !dilations || !ws)
         return fail(PM_EINVAL, "null argument");
     const int Cp = pad32(C);
@@ -1180,11 +1181,47 @@ extern "C" int pm_block_cl(
         a.scratch = (char*)ws + 3 * per;
         a.scratch_bytes = ws_bytes - 3 * per;
     }
+    int act16_done = 0;
+    if (act16) {
+        a.act16 = act16; a.act16_type = act_dtype; a.act16_done = &act16_done;
+    }
     hipError_t e = launch_block3(dtype, Cp, K, a, s);
     if (e == hipErrorNotSupported)
         return fail(PM_EINVAL, "no whole-Block kernel for this shape");
     HIP_TRY(e);
+    if (act16 && !act16_done)
+        return fail(PM_ESTATE, "the launch did not take the skewed walk: `out` "
+                    "holds the fp32 result, the 16-bit operand copy was not "
+                    "written");
     return PM_OK;
+}
+
+extern "C" int pm_block_cl(
+    int dtype, const float* x, float* out, const float* const* w1,
+    const float* const* b1, const float* const* w2, const float* const* b2,
+    const int* dilations, int niter, int B, int L, int C, int K, int mode,
+    float scale, void* ws, size_t ws_bytes, void* stream) {
+    return block_cl_impl(dtype, x, out, w1, b1, w2, b2, dilations, niter, B, L,
+                         C, K, mode, scale, ws, ws_bytes, stream, nullptr, 0);
+}
+
+// pm_block_cl whose result leaves as the NEXT upsampler's MFMA operand instead
+// of fp32 (Block3Args::act16): act16 (B, L, c_pad) 16-bit = cvt(lrelu(result)),
+// act_dtype PM_F16 or PM_BF16; `out` is read (mode 2) and not written. Only the
+// skewed walk does this: PM_ESTATE (and the plain fp32 result in `out`) when the
+// launcher took another kernel.
+extern "C" int pm_block_act16_cl(
+    int dtype, int act_dtype, const float* x, float* out, void* act16,
+    const float* const* w1, const float* const* b1, const float* const* w2,
+    const float* const* b2, const int* dilations, int niter, int B, int L,
+    int C, int K, int mode, float scale, void* ws, size_t ws_bytes,
+    void* stream) {
+    if (!act16) return fail(PM_EINVAL, "null argument");
+    if (act_dtype != PM_F16 && act_dtype != PM_BF16)
+        return fail(PM_EINVAL, "act_dtype must be PM_F16 or PM_BF16");
+    return block_cl_impl(dtype, x, out, w1, b1, w2, b2, dilations, niter, B, L,
+                         C, K, mode, scale, ws, ws_bytes, stream, act16,
+                         act_dtype);
 }
 
 // Whole MRF ResidualBlock (hifigan.py:141-145): out = (B_3(x) + B_7(x) +
@@ -1284,11 +1321,12 @@ extern "C" int pm_input_conv_cl(
     return PM_OK;
 }
 
-extern "C" int pm_conv_transpose_cl(
-    int dtype, const float* x, float* out, const float* w, const float* bias,
-    int B, int L, int c_in, int c_out, int r, int lrelu, void* ws,
-    size_t ws_bytes, void* stream) {
-    if (!x || !out || !w || !bias || !ws) return fail(PM_EINVAL, "null argument");
+static int conv_transpose_cl_impl(
+    int dtype, const float* x, const void* x16, float* out, const float* w,
+    const float* bias, int B, int L, int c_in, int c_out, int r, int lrelu,
+    void* ws, size_t ws_bytes, void* stream) {
+    if ((!x && !x16) || !out || !w || !bias || !ws)
+        return fail(PM_EINVAL, "null argument");
     if (r < 2 || (r & 1)) return fail(PM_EINVAL, "rate %d unsupported", r);
     if (ws_bytes < pm_op_workspace_bytes(c_in, c_out, 2 * r))
         return fail(PM_ENOMEM, "workspace too small");
@@ -1311,8 +1349,35 @@ extern "C" int pm_conv_transpose_cl(
     a.gbias_batch = 1; a.B = B; a.L = L; a.Lout = L; a.Cin = g.cin_pad;
     a.M = g.M; a.lrelu = lrelu; a.pad = 1;
     a.phase_c = g.cout_pad; a.phase_p = r / 2; a.phase_r = r;
+    if (x16) {
+        if (esz(dtype) != 2 || cfg == 4)
+            return fail(PM_EINVAL, "a 16-bit operand input needs a 16-bit "
+                        "operand type and the narrow upsampler kernel");
+        a.x16 = x16;
+    }
     HIP_TRY(launch_single(dtype, 1, g.ch, cfg, a, s));
     return PM_OK;
+}
+
+extern "C" int pm_conv_transpose_cl(
+    int dtype, const float* x, float* out, const float* w, const float* bias,
+    int B, int L, int c_in, int c_out, int r, int lrelu, void* ws,
+    size_t ws_bytes, void* stream) {
+    if (!x) return fail(PM_EINVAL, "null argument");
+    return conv_transpose_cl_impl(dtype, x, nullptr, out, w, bias, B, L, c_in,
+                                  c_out, r, lrelu, ws, ws_bytes, stream);
+}
+
+// pm_conv_transpose_cl on an input that already holds the operand values:
+// x16_cl (B, L, c_in_pad) in the operand type `dtype` = cvt(lrelu(x)), as
+// pm_block_act16_cl writes it - staged as it is (SingleArgs::x16).
+extern "C" int pm_conv_transpose_x16_cl(
+    int dtype, const void* x16, float* out, const float* w, const float* bias,
+    int B, int L, int c_in, int c_out, int r, void* ws, size_t ws_bytes,
+    void* stream) {
+    if (!x16) return fail(PM_EINVAL, "null argument");
+    return conv_transpose_cl_impl(dtype, nullptr, x16, out, w, bias, B, L, c_in,
+                                  c_out, r, 1, ws, ws_bytes, stream);
 }
 
 extern "C" int pm_out_conv_tanh(

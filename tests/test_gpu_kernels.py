@@ -562,3 +562,105 @@ def test_f16_operands_saturate(device):
         return xt + x
     check(rel_err(got, saturated_oracle()), TOL['f16'], 'iteration:f16',
           'saturated')
+
+
+@pytest.mark.parametrize('act', ['f16', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+@pytest.mark.parametrize('channels,kernel_size', [(128, 11), (64, 11), (64, 7)])
+def test_block_output_as_next_operand(device, dtype, act, channels, kernel_size):
+    """The 16-bit hand-over between a stage's last Block launch and the next
+    upsampler (Block3Args::act16 / SingleArgs::x16, hifigan.py:100-106 stages
+    lrelu(stage output)): the skewed walk writes cvt(lrelu(result)) in the NEXT
+    stage's operand type instead of the fp32 tensor - bit for bit what rounding
+    the fp32 result gives - and leaves `out` alone; the r = 2 upsampler fed with
+    it equals, bit for bit, the one that stages the fp32 tensor itself. Outside
+    the skewed walk the request is refused, not ignored."""
+    _lib = lib()
+    gen = torch.Generator().manual_seed(3000 + channels + kernel_size)
+    dilations = (1, 3, 5)
+    state, tensors = block_fixture(channels, kernel_size, gen, device)
+
+    def pointers(name):
+        return (ctypes.c_void_p * 3)(*[t.data_ptr() for t in tensors[name]])
+
+    dil = (ctypes.c_int * 3)(*dilations)
+    weights = 3 * _lib.lib().pm_op_workspace_bytes(
+        channels, channels, kernel_size)
+    ws = torch.empty(
+        weights + _lib.lib().pm_walk_scratch_bytes(2), dtype=torch.uint8,
+        device=device)
+    columns = 512 if channels == 64 else 256
+    length = 7 * columns + 45
+    x = torch.randn(2, channels, length, generator=gen)
+    prev = torch.randn(2, channels, length, generator=gen)
+    x_cl, prev_cl = to_cl(x).to(device), to_cl(prev).to(device)
+    torch_type = {'f16': torch.float16, 'bf16': torch.bfloat16}[act]
+
+    def block(out, act16=None, size=None):
+        args = [pointers('w1'), pointers('b1'), pointers('w2'), pointers('b2'),
+                dil, 3, 2, length, channels, kernel_size, 2, 1 / 3,
+                ws.data_ptr(), size or ws.numel(), _lib.stream()]
+        if act16 is None:
+            code = _lib.lib().pm_block_cl(
+                _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out), *args)
+        else:
+            code = _lib.lib().pm_block_act16_cl(
+                _lib.DTYPES[dtype], _lib.DTYPES[act], _lib.ptr(x_cl),
+                _lib.ptr(out), act16.data_ptr(), *args)
+        torch.cuda.synchronize()
+        return code
+
+    try:
+        _lib.check(_lib.lib().pm_debug_force(2, 0))
+        _lib.check(_lib.lib().pm_debug_skew(1))
+        plain = prev_cl.clone()
+        _lib.check(block(plain))
+        out = prev_cl.clone()
+        act16 = torch.full(
+            (2, length, channels), 0x7fff, dtype=torch.int16, device=device)
+        _lib.check(block(out, act16))
+        assert torch.equal(out, prev_cl)            # read, not written
+        want = F.leaky_relu(plain, .1)
+        if act == 'f16':
+            want = want.clamp(max=65504.)
+        want = want.to(torch_type).view(torch.int16)
+        assert torch.equal(act16, want)
+        # the consumer: the next stage's r = 2 upsampler, operand type `act`
+        c_out = channels // 2
+        w = torch.randn(channels, c_out, 4, generator=gen) / (2 * channels) ** .5
+        bias = torch.randn(c_out, generator=gen) * .1
+        wd, bd = w.to(device), bias.to(device)
+        up_ws = workspace(device, channels, c_out, 4)
+        outs = []
+        for source in ('fp32', 'x16'):
+            up = torch.zeros(2, 2 * length, pad32(c_out), device=device)
+            if source == 'fp32':
+                _lib.check(_lib.lib().pm_conv_transpose_cl(
+                    _lib.DTYPES[act], _lib.ptr(plain), _lib.ptr(up),
+                    _lib.ptr(wd), _lib.ptr(bd), 2, length, channels, c_out, 2,
+                    1, up_ws.data_ptr(), up_ws.numel(), _lib.stream()))
+            else:
+                _lib.check(_lib.lib().pm_conv_transpose_x16_cl(
+                    _lib.DTYPES[act], act16.data_ptr(), _lib.ptr(up),
+                    _lib.ptr(wd), _lib.ptr(bd), 2, length, channels, c_out, 2,
+                    up_ws.data_ptr(), up_ws.numel(), _lib.stream()))
+            torch.cuda.synchronize()
+            outs.append(up)
+        assert torch.equal(outs[0], outs[1])
+        expected = F.conv_transpose1d(
+            F.leaky_relu(from_cl(plain, channels).cpu(), .1), w, bias, stride=2,
+            padding=1)
+        check(rel_err(from_cl(outs[1], c_out), expected), TOL_UP[act],
+              f'conv_transpose:{act}', ('x16', channels))
+        # no scratch behind the workspace -> another kernel -> refused
+        _lib.check(_lib.lib().pm_debug_skew(-1))
+        other = prev_cl.clone()
+        if (channels, kernel_size) == (128, 11):
+            # (this Block exists as a skewed walk only)
+            assert block(other, act16) == _lib.PM_EINVAL
+        else:
+            assert block(other, act16) == _lib.PM_ESTATE
+            assert torch.equal(other, plain)        # the fp32 result instead
+    finally:
+        _lib.check(_lib.lib().pm_debug_force(0, 0))
+        _lib.check(_lib.lib().pm_debug_skew(0))
