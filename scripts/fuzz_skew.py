@@ -18,6 +18,7 @@ from promonet_amd import _lib  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+WIDE = len(sys.argv) > 3 and sys.argv[3] == 'wide'   # fp32 / f16x3 shapes
 device = torch.device('cuda:0')
 lib = _lib.lib()
 bad = skipped = 0
@@ -26,6 +27,9 @@ for trial in range(trials):
     k = rng.choice((3, 7, 11)) if channels <= 128 else rng.choice((3, 7))
     if channels in (64, 50) and k == 3:
         k = 7                       # (C = 64 k 3 has a 4-wave tiling only)
+    if WIDE:
+        channels = rng.choice((32, 64, 20, 50))
+        k = rng.choice((3, 7, 11))
     niter = rng.randint(1, 3)
     h2 = k // 2
     dmax = min(5, 30 // h2 - 1)
@@ -52,6 +56,10 @@ for trial in range(trials):
     ws = torch.empty(weights + lib.pm_walk_scratch_bytes(batch),
                      dtype=torch.uint8, device=device)
     dtype = rng.choice(('bf16', 'f16'))
+    if WIDE:
+        # the 4-byte operand layouts (exact fp32, split f16): whole-Block
+        # tilings - and the skewed walk - exist for C <= 64 (every k)
+        dtype = rng.choice(('fp32', 'f16x3'))
     outs = []
     for skew, size in ((1, ws.numel()), (-1, weights)):
         out = prev.clone().to(device)
