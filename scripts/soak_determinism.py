@@ -19,7 +19,7 @@ device = torch.device('cuda:0')
 state = oracle.random_state(seed=0)
 inputs = [t.to(device) for t in oracle.synthetic_inputs(32, 861, seed=1234)]
 bad = 0
-for dtype in ('bf16', 'f16'):
+for dtype in ('bf16', 'f16', 'checkpoint'):
     promonet_amd.configure(COMPUTE_DTYPE=dtype)
     model = promonet_amd.model.Generator()
     model.load_state_dict(state)
