@@ -166,7 +166,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 #define PM_BDEPTH 2     // B fragments in flight: this many k16 steps' worth
 #endif
 template <class ET, int KT, int KC, int MTW, int NTW, int G, int S,
-          class Hook = NoHook>
+          class Hook = NoHook, int BDO = 0>
 __device__ __forceinline__ void mma_taps(
     floatx16 (&acc)[MTW][NTW], const char* bptr, const int tap_bytes,
     const typename ET::frag_t* __restrict__ wptr, const int w_mt_stride,
@@ -177,7 +177,7 @@ __device__ __forceinline__ void mma_taps(
     // (split-f16: fragments are twice as wide and a step is three MFMAs per
     // tile; the second B buffer is what spilled in the whole-MRF kernel, and
     // the SIMD's other wave covers the LDS round trip)
-    constexpr int BD = ET::ID == 3 && NTW >= 2 ? 1 : PM_BDEPTH;
+    constexpr int BD = BDO ? BDO : (ET::ID == 3 && NTW >= 2 ? 1 : PM_BDEPTH);
     static_assert(NS % G == 0, "group size must divide the step count");
     static_assert(NS >= BD, "fewer steps than B buffers");
     frag_t abuf[2][G][MTW];   // A (weights): one GROUP ahead, from L2
@@ -1818,11 +1818,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
     constexpr int AL = GE::AL;
     constexpr int S = GE::S;
     constexpr int QS = S / 16;
+    // (split f16: weight prefetch depth 1 - depth 2 spills at k 11 and measures
+    // the same; its B fragments two steps deep: -3 % at k 11, profiles/r04/ab_x3_skew.txt)
     constexpr int G = (ET::ESZ == 4) ? (ET::ID == 3 ? 1 : 2) : KC;
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;
     constexpr int W_MT_STRIDE = W_BIAS + 64;
     constexpr int AUX = 16;        // sc1: served by the L2, never by this CU's L1
+    // (B-fragment depth of the MFMA loops: the default rule, or - split f16,
+    // where this kernel has the registers the fused whole-MRF kernel lacks - 2)
+    constexpr int PM_SKEW_BD = ET::ID == 3 ? 2 : 0;
     static_assert(NTW >= 2, "the trunk shift needs two tiles per wave");
     // (the exchange slot is 64 B x 64 rows of the receiving wave's part of t: a
     // row of its MTW x 32 channels is 64 B with 16-bit operands, 128 B with the
@@ -2051,7 +2056,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
                 const int col_off = col_offset(t1);
 #pragma unroll 1
                 for (int c = 0; c < NCH; ++c)
-                    mma_taps<ET, K, KC, MTW, NTW, G, S>(
+                    mma_taps<ET, K, KC, MTW, NTW, G, S, NoHook, PM_SKEW_BD>(
                         acc, abuf + (AL + H2 - H2 * d) * S + col_off + c * CH * ET::ESZ,
                         d * S, w1 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
                         c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
@@ -2116,7 +2121,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
                 const int col_off = col_offset(t2);
 #pragma unroll 1
                 for (int c = 0; c < NCH; ++c)
-                    mma_taps<ET, K, KC, MTW, NTW, G, S>(
+                    mma_taps<ET, K, KC, MTW, NTW, G, S, NoHook, PM_SKEW_BD>(
                         trunk, tbuf + col_off + c * CH * ET::ESZ, S,
                         w2 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
                         c + 1 < NCH ? w2 + (size_t)(c + 1) * W_CHUNK
