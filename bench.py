@@ -45,6 +45,8 @@ FARGAN_FLOP_PER_SAMPLE = 73_843
 # conv 256x520 + its GLU 256x256, 3 x (GRU 768x384 + 768x256 + GLU 256x256),
 # skip 256x1152 + GLU, output 64x256; + 1/4 of the per-frame conditioning net
 FARGAN_WEIGHTS = 2_246_656 + (2 * 371 * 371 + 512 * 371) // 4
+# of those: 3 x (768 x 384 + 768 x 256) GRU + 5 x 256 x 256 GLU gate weights
+FARGAN_MIXED_F16_WEIGHTS = 3 * 768 * 640 + 5 * 256 * 256
 # dense MFMA peaks per USEFUL flop (f16x3: three MFMAs per product)
 PEAK_TFLOPS = {'f16': 2500., 'bf16': 2500., 'fp32': 157.3,
                'f16x3': 2500. / 3}
@@ -67,7 +69,7 @@ def parse_args():
                              'upsampling stage joined by + (hifigan, default '
                              'bf16; f16+f16+f16+f16x3 = the trained-checkpoint '
                              'mode, DESIGN.md section 3) / '
-                             'stored weight type f16|fp32 (fargan, default '
+                             'stored weight type f16|mixed|fp32 (fargan, default '
                              'fp32; its math is always fp32)')
     parser.add_argument('--batch', type=int, default=32,
                         help='utterances per GPU')
@@ -397,7 +399,7 @@ def main():
     samples_per_step = args.batch * frames * promonet_amd.HOPSIZE
 
     if fargan:
-        weight_dtype = 'f16' if args.dtype == 'f16' else 'fp32'
+        weight_dtype = args.dtype if args.dtype in ('f16', 'mixed') else 'fp32'
         promonet_amd.configure(MODEL='fargan', FARGAN_WEIGHT_DTYPE=weight_dtype)
     else:
         promonet_amd.configure(COMPUTE_DTYPE=args.dtype)
@@ -587,7 +589,12 @@ def main():
             'vs_baseline': None,
             'dtype': dtype,
             'accuracy': (
-                'fp32 arithmetic' if fargan else
+                'fp32 arithmetic; weights stored as '
+                f'{promonet_amd.FARGAN_WEIGHT_DTYPE} (max-abs against the '
+                'reference over a whole 10 s utterance, random-init weights: '
+                'fp32 2e-6, mixed 6e-6, f16 6.7e-5 - '
+                'tests/test_gpu_fargan.py::test_full_size_config5)'
+                if fargan else
                 f'{args.dtype} operands at the 1e-4 max-abs gate on RANDOM-INIT '
                 'weights (audio peak 0.017: tests/test_gpu_model.py::'
                 'test_full_size_every_sample); at trained-checkpoint scale see '
@@ -643,8 +650,12 @@ def main():
             times = [a.elapsed_time(b) for a, b in forward_events]
             avg_ms = sum(times) / len(times)
             steps = frames * 4
-            wbytes = FARGAN_WEIGHTS * (
-                2 if promonet_amd.FARGAN_WEIGHT_DTYPE == 'f16' else 4)
+            # ('mixed': the GRU cells and the GLU gates - 1 802 240 of the
+            # weights a sub-frame step streams - are stored f16, the rest fp32)
+            wbytes = {
+                'f16': FARGAN_WEIGHTS * 2,
+                'mixed': FARGAN_WEIGHTS * 4 - FARGAN_MIXED_F16_WEIGHTS * 2,
+            }.get(promonet_amd.FARGAN_WEIGHT_DTYPE, FARGAN_WEIGHTS * 4)
             # compulsory HBM bytes of one launch: features in, audio out, the
             # weights once (they stay L2-resident for all 3 444 steps)
             hbm_bytes = args.batch * frames * (128 * 4 + 256 * 4) + wbytes

@@ -321,8 +321,13 @@ int pm_stretch_grid(const float* ppg, int ppg_rows, const int* indices,
 
 /* ---- FARGAN vocoder engine: replaces promonet.model.FARGAN ---------------
  * (promonet/model/fargan.py, selected by config/fargan.py MODEL = 'fargan').
- * One persistent workgroup per utterance; weight_dtype PM_F32 or PM_F16 is
- * the STORAGE type of the streamed weights (math is fp32).                 */
+ * One persistent workgroup per utterance; weight_dtype PM_F32, PM_F16 or
+ * PM_FARGAN_MIXED is the STORAGE type of the streamed weights (math is fp32).
+ * PM_FARGAN_MIXED keeps the conditioning network, the framewise conv, the
+ * skip dense and the output layer (fargan.py:139-160, :349-372, :317-333) in
+ * fp32 and stores the three GRU cells and every GLU gate (:212-223, :375-388)
+ * - 80 % of the per-step weight stream - as f16.                            */
+#define PM_FARGAN_MIXED 16
 typedef struct pm_fargan_s* pm_fargan_t;
 int pm_fargan_create(int num_features, int global_channels, int weight_dtype,
                      pm_fargan_t* out);

@@ -13,7 +13,10 @@ LIB_PATH = Path(__file__).parent / 'lib' / 'libpromonet_hip.so'
 
 PM_F32, PM_F16, PM_BF16, PM_F16X3 = 0, 1, 2, 3
 DTYPES = {'fp32': PM_F32, 'f32': PM_F32, 'f16': PM_F16, 'fp16': PM_F16,
-          'bf16': PM_BF16, 'f16x3': PM_F16X3}
+          'bf16': PM_BF16, 'f16x3': PM_F16X3,
+          # FARGAN weight storage only (PM_FARGAN_MIXED, promonet_hip.h):
+          # GRU cells / GLU gates f16, the rounding-sensitive layers fp32
+          'mixed': 16}
 MAX_STAGES, MAX_RESBLOCKS, MAX_DILATIONS = 8, 4, 4
 SPARSE_METHODS = {None: 0, 'percentile': 1, 'constant': 2, 'topk': 3}
 

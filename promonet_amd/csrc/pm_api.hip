@@ -1872,6 +1872,7 @@ struct FLayer {
     bool normed;         // weight-normed Linear: accepts weight_g + weight_v
     int rows, cols, rpad, kpad;
     int kw = 0;              // > 0: also packed K-split, 8 x (rpad x kw)
+    bool insensitive = false;  // stored f16 under PM_FARGAN_MIXED (GRU, gates)
     size_t offset = 0;       // element offsets into the one weight buffer
     size_t offset_k = 0;
     float* tmp_g = nullptr;
@@ -1881,6 +1882,8 @@ struct FLayer {
 
 struct pm_fargan_s {
     void* weights = nullptr;   // every packed layer (FarganWeights layout)
+    void* weights_i = nullptr; // PM_FARGAN_MIXED: the f16-stored layers (same
+                               // element offsets; only their regions are used)
     int nfeat, G, dtype;
     int mode = 0;        // 0 auto, 1 one workgroup per utterance, 2 clusters
     std::vector<FLayer> layers;
@@ -1914,6 +1917,8 @@ static std::vector<FLayer> fargan_layers(int nin) {
     l[4].kw = 32;                                   // framewise conv GLU gate
     l[11].kw = l[12].kw = l[13].kw = 32;            // GRU GLU gates
     l[16].kw = 32;                                  // output layer
+    // FgTypes<FgMixed>::I (pm_fargan.h): the GRU cells and the GLU gates
+    for (int i : {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15}) l[i].insensitive = true;
     // offsets = FarganWeights<>: row-packed layers in table order, then the
     // K-split copies
     size_t at = 0;
@@ -1937,8 +1942,10 @@ extern "C" int pm_fargan_create(
         return fail(PM_EINVAL,
                     "FARGAN kernel is built for 113 + 258 conditioning "
                     "channels (config/fargan.py)");
-    if (weight_dtype != PM_F32 && weight_dtype != PM_F16)
-        return fail(PM_EINVAL, "weight dtype must be PM_F32 or PM_F16");
+    if (weight_dtype != PM_F32 && weight_dtype != PM_F16 &&
+        weight_dtype != PM_FARGAN_MIXED)
+        return fail(PM_EINVAL,
+                    "weight dtype must be PM_F32, PM_F16 or PM_FARGAN_MIXED");
     auto* h = new pm_fargan_s();
     h->nfeat = num_features; h->G = global_channels; h->dtype = weight_dtype;
     h->layers = fargan_layers(num_features + global_channels);
@@ -1962,6 +1969,7 @@ extern "C" int pm_fargan_create(
 extern "C" int pm_fargan_destroy(pm_fargan_t h) {
     if (!h) return PM_OK;
     if (h->weights) hipFree(h->weights);
+    if (h->weights_i) hipFree(h->weights_i);
     for (auto& l : h->layers) {
         if (l.tmp_g) hipFree(l.tmp_g);
         if (l.tmp_v) hipFree(l.tmp_v);
@@ -1972,10 +1980,10 @@ extern "C" int pm_fargan_destroy(pm_fargan_t h) {
 
 template <class WT>
 static hipError_t fargan_pack_t(
-    pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) {
+    void* buffer, FLayer& l, const float* w, hipStream_t s) {
     const int gru = l.rows == 768 ? 1 : 0;   // gate-interleaved GRU rows
     const size_t elems = (size_t)l.rpad * l.kpad;
-    WT* base = (WT*)h->weights;
+    WT* base = (WT*)buffer;
     hipLaunchKernelGGL(pm_fargan_pack_kernel<WT>,
                        dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s,
                        w, base + l.offset, l.rows, l.cols, l.rpad, l.kpad, gru,
@@ -1995,9 +2003,15 @@ static hipError_t fargan_pack_t(
 static int fargan_pack(pm_fargan_t h, FLayer& l, const float* w, hipStream_t s) {
     if (!h->weights)
         HIP_TRY(hipMalloc(&h->weights, FarganWeights<float>::TOTAL *
-                                           (h->dtype == PM_F32 ? 4 : 2)));
-    if (h->dtype == PM_F32) HIP_TRY(fargan_pack_t<float>(h, l, w, s));
-    else HIP_TRY(fargan_pack_t<_Float16>(h, l, w, s));
+                                           (h->dtype == PM_F16 ? 2 : 4)));
+    if (h->dtype == PM_FARGAN_MIXED && !h->weights_i)
+        HIP_TRY(hipMalloc(&h->weights_i, FarganWeights<float>::TOTAL * 2));
+    if (h->dtype == PM_FARGAN_MIXED && l.insensitive)
+        HIP_TRY(fargan_pack_t<_Float16>(h->weights_i, l, w, s));
+    else if (h->dtype == PM_F16)
+        HIP_TRY(fargan_pack_t<_Float16>(h->weights, l, w, s));
+    else
+        HIP_TRY(fargan_pack_t<float>(h->weights, l, w, s));
     l.has = true;
     return PM_OK;
 }
@@ -2125,7 +2139,9 @@ template <class WT>
 static int fargan_launch(
     pm_fargan_t h, const FarganArgs& a, hipStream_t s, void* cluster_state) {
     FarganWeights<WT> w;
-    w.base = (const WT*)h->weights;
+    w.base = (const typename FarganWeights<WT>::S*)h->weights;
+    w.base_i = (const typename FarganWeights<WT>::I*)(
+        h->weights_i ? h->weights_i : h->weights);
     if (cluster_state) {
         // counters / payload / error word are re-initialised on every call
         HIP_TRY(hipMemsetAsync(cluster_state, 0, fargan_state_bytes(), s));
@@ -2215,7 +2231,8 @@ static int fargan_forward_impl(
     a.global_batch = gbatch; a.previous_batch = pbatch;
     a.lengths = lengths;
     return h->dtype == PM_F32 ? fargan_launch<float>(h, a, s, cluster_state)
-                              : fargan_launch<_Float16>(h, a, s, cluster_state);
+         : h->dtype == PM_F16 ? fargan_launch<_Float16>(h, a, s, cluster_state)
+                              : fargan_launch<FgMixed>(h, a, s, cluster_state);
 }
 
 extern "C" int pm_fargan_forward(

@@ -131,9 +131,30 @@ __global__ __launch_bounds__(256) void pm_fargan_pack_kernel(
 // of them exhausted the scalar registers and spilled into vector registers.
 // Order = the layer table of pm_api.hip (fargan_layers); the K-split copies
 // used by the cluster kernel follow the row-packed layers.
+// Mixed storage (round 4): the matrices whose rounding the audio does not feel
+// - the three GRU cells' W_ih / W_hh (U(-1/16, 1/16) entries in front of a
+// sigmoid / tanh) and every GLU gate (in front of a sigmoid) - are stored f16,
+// the ones it does feel - conditioning network, framewise conv, skip dense,
+// output layer (orthogonal, feeding tanh outputs directly) - stay fp32.
+// 80 % of the per-step weight stream is of the first kind: 5.4 MB instead of
+// 9.0 MB per sub-frame step at 1/10 of the all-f16 storage error
+// (scripts/fargan_weight_sensitivity.py: 6e-6 against 6.7e-5 max-abs).
+struct FgMixed {};
+template <class WT> struct FgTypes { typedef WT S; typedef WT I; };
+template <> struct FgTypes<FgMixed> { typedef float S; typedef _Float16 I; };
+
 template <class WT>
 struct FarganWeights {
-    const WT* base;
+    typedef typename FgTypes<WT>::S S;   // rounding-sensitive layers
+    typedef typename FgTypes<WT>::I I;   // insensitive layers (GRU, gates)
+    const S* base;
+    const I* base_i;   // read only when I differs from S (same element offsets)
+    __device__ __forceinline__ const I* ibase() const {
+        if constexpr (std::is_same<S, I>::value)
+            return reinterpret_cast<const I*>(base);
+        else
+            return base_i;
+    }
     static constexpr size_t COND0 = 0;                         // 384 x 376
     static constexpr size_t COND1 = COND0 + 384 * 376;         // 384 x 376
     static constexpr size_t COND2 = COND1 + 384 * 376;         // 512 x 376
@@ -151,34 +172,34 @@ struct FarganWeights {
     static constexpr size_t K_GRU_GLU = K_FWGLU + 8 * 256 * 32;    // 3 x 8 x 256 x 32
     static constexpr size_t K_OUT = K_GRU_GLU + 3 * 8 * 256 * 32;  // 8 x 64 x 32
     static constexpr size_t TOTAL = K_OUT + 8 * 64 * 32;
-    __device__ __forceinline__ const WT* cond(int i) const {
+    __device__ __forceinline__ const S* cond(int i) const {
         return base + (i == 0 ? COND0 : i == 1 ? COND1 : COND2);
     }
-    __device__ __forceinline__ const WT* fwconv() const { return base + FWCONV; }
-    __device__ __forceinline__ const WT* fwconv_glu() const { return base + FWGLU; }
-    __device__ __forceinline__ const WT* gru_ih(int n) const {
-        return base + GRU_IH + (size_t)n * (768 * 384);
+    __device__ __forceinline__ const S* fwconv() const { return base + FWCONV; }
+    __device__ __forceinline__ const I* fwconv_glu() const { return ibase() + FWGLU; }
+    __device__ __forceinline__ const I* gru_ih(int n) const {
+        return ibase() + GRU_IH + (size_t)n * (768 * 384);
     }
-    __device__ __forceinline__ const WT* gru_hh(int n) const {
-        return base + GRU_HH + (size_t)n * (768 * 256);
+    __device__ __forceinline__ const I* gru_hh(int n) const {
+        return ibase() + GRU_HH + (size_t)n * (768 * 256);
     }
-    __device__ __forceinline__ const WT* gru_glu(int n) const {
-        return base + GRU_GLU + (size_t)n * (256 * 256);
+    __device__ __forceinline__ const I* gru_glu(int n) const {
+        return ibase() + GRU_GLU + (size_t)n * (256 * 256);
     }
-    __device__ __forceinline__ const WT* skip() const { return base + SKIP; }
-    __device__ __forceinline__ const WT* skip_glu() const { return base + SKIP_GLU; }
-    __device__ __forceinline__ const WT* out() const { return base + OUT; }
+    __device__ __forceinline__ const S* skip() const { return base + SKIP; }
+    __device__ __forceinline__ const I* skip_glu() const { return ibase() + SKIP_GLU; }
+    __device__ __forceinline__ const S* out() const { return base + OUT; }
     // K-split sub-matrix of member g
-    __device__ __forceinline__ const WT* k_cond1(int g) const {
+    __device__ __forceinline__ const S* k_cond1(int g) const {
         return base + K_COND1 + (size_t)g * (384 * 48);
     }
-    __device__ __forceinline__ const WT* k_fwconv_glu(int g) const {
-        return base + K_FWGLU + (size_t)g * (256 * 32);
+    __device__ __forceinline__ const I* k_fwconv_glu(int g) const {
+        return ibase() + K_FWGLU + (size_t)g * (256 * 32);
     }
-    __device__ __forceinline__ const WT* k_gru_glu(int n, int g) const {
-        return base + K_GRU_GLU + (size_t)(n * 8 + g) * (256 * 32);
+    __device__ __forceinline__ const I* k_gru_glu(int n, int g) const {
+        return ibase() + K_GRU_GLU + (size_t)(n * 8 + g) * (256 * 32);
     }
-    __device__ __forceinline__ const WT* k_out(int g) const {
+    __device__ __forceinline__ const S* k_out(int g) const {
         return base + K_OUT + (size_t)g * (64 * 32);
     }
 };
@@ -204,6 +225,8 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
     FarganArgs a, FarganWeights<WT> w) {
     constexpr int NT = FG_THREADS;
     constexpr int CPAD = 376;   // 371 conditioning inputs, padded to x8
+    typedef typename FgTypes<WT>::S WS;
+    typedef typename FgTypes<WT>::I WI;
     __shared__ __attribute__((aligned(16))) float condin[CPAD];
     __shared__ __attribute__((aligned(16))) float c1[CPAD];
     __shared__ __attribute__((aligned(16))) float c2[CPAD];
@@ -248,16 +271,16 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
         if (tid == 0) s_period = (int)rintf(row[a.nfeat]);   // fargan.py:94
         __syncthreads();
         {
-            part[tid] = fg_gemv<WT, 384, 2>(w.cond(0), condin, condin, CPAD, CPAD, tid);
+            part[tid] = fg_gemv<WS, 384, 2>(w.cond(0), condin, condin, CPAD, CPAD, tid);
             __syncthreads();
             if (tid < nin) c1[tid] = tanhf(part[tid] + part[tid + 384]);
             __syncthreads();
-            part[tid] = fg_gemv<WT, 384, 2>(w.cond(1), c1, c1, CPAD, CPAD, tid);
+            part[tid] = fg_gemv<WS, 384, 2>(w.cond(1), c1, c1, CPAD, CPAD, tid);
             __syncthreads();
             if (tid < nin) c2[tid] = tanhf(part[tid] + part[tid + 384]);
             __syncthreads();
             if (tid < 512)
-                cond[tid] = tanhf(fg_gemv<WT, 512, 1>(w.cond(2), c2, c2, CPAD, CPAD, tid));
+                cond[tid] = tanhf(fg_gemv<WS, 512, 1>(w.cond(2), c2, c2, CPAD, CPAD, tid));
             __syncthreads();
         }
         const int period = s_period;
@@ -285,11 +308,11 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
             __syncthreads();
 
             // ---- framewise conv: Linear(520 -> 256), tanh, GLU (:349-372) ----
-            part[tid] = fg_gemv<WT, 256, 3>(w.fwconv(), subin, subin, 520, 520, tid);
+            part[tid] = fg_gemv<WS, 256, 3>(w.fwconv(), subin, subin, 520, 520, tid);
             __syncthreads();
             if (tid < 256) f1[tid] = tanhf(part[tid] + part[tid + 256] + part[tid + 512]);
             __syncthreads();
-            part[tid] = fg_gemv<WT, 256, 3>(w.fwconv_glu(), f1, f1, 256, 256, tid);
+            part[tid] = fg_gemv<WI, 256, 3>(w.fwconv_glu(), f1, f1, 256, 256, tid);
             __syncthreads();
             if (tid < 256)
                 skipbuf[768 + tid] = f1[tid] * fg_sigmoid(
@@ -302,9 +325,9 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
                 // input [x | lookback | previous subframe]; x = fwconv output
                 // or the previous GLU output
                 const float* xa = n == 0 ? skipbuf + 768 : skipbuf + (n - 1) * 256;
-                part[tid] = fg_gemv<WT, 768, 1>(
+                part[tid] = fg_gemv<WI, 768, 1>(
                     w.gru_ih(n), xa, skipbuf + 1024, 256, 384, tid);
-                part2[tid] = fg_gemv<WT, 768, 1>(
+                part2[tid] = fg_gemv<WI, 768, 1>(
                     w.gru_hh(n), hid[n], hid[n], 256, 256, tid);
                 __syncthreads();
                 if (tid < 256) {
@@ -316,7 +339,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
                     hid[n][tid] = (1.f - z) * nn + z * hid[n][tid];
                 }
                 __syncthreads();
-                part[tid] = fg_gemv<WT, 256, 3>(w.gru_glu(n), hid[n], hid[n], 256, 256, tid);
+                part[tid] = fg_gemv<WI, 256, 3>(w.gru_glu(n), hid[n], hid[n], 256, 256, tid);
                 __syncthreads();
                 if (tid < 256)
                     skipbuf[n * 256 + tid] = hid[n][tid] * fg_sigmoid(
@@ -325,17 +348,17 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
             }
 
             // ---- skip connection + output layer (:317-333) ----
-            part[tid] = fg_gemv<WT, 256, 3>(w.skip(), skipbuf, skipbuf, FG_SKIP, FG_SKIP, tid);
+            part[tid] = fg_gemv<WS, 256, 3>(w.skip(), skipbuf, skipbuf, FG_SKIP, FG_SKIP, tid);
             __syncthreads();
             if (tid < 256) f1[tid] = tanhf(part[tid] + part[tid + 256] + part[tid + 512]);
             __syncthreads();
-            part[tid] = fg_gemv<WT, 256, 3>(w.skip_glu(), f1, f1, 256, 256, tid);
+            part[tid] = fg_gemv<WI, 256, 3>(w.skip_glu(), f1, f1, 256, 256, tid);
             __syncthreads();
             if (tid < 256)
                 f1[tid] = f1[tid] * fg_sigmoid(
                     part[tid] + part[tid + 256] + part[tid + 512]);
             __syncthreads();
-            part[tid] = fg_gemv<WT, 64, 12>(w.out(), f1, f1, 256, 256, tid);
+            part[tid] = fg_gemv<WS, 64, 12>(w.out(), f1, f1, 256, 256, tid);
             __syncthreads();
             if (tid < FG_SUB) {
                 float v = 0.f;
@@ -746,6 +769,8 @@ template <class WT, int U>
 __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
     FarganClusterArgs ca, FarganWeights<WT> w) {
     const FarganArgs& a = ca.f;
+    typedef typename FgTypes<WT>::S WS;
+    typedef typename FgTypes<WT>::I WI;
     constexpr int NT = FG_THREADS;
     constexpr int CPAD = 376;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // FgLds[U]
@@ -822,7 +847,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
             __syncthreads();
             float v[U], m[U], tot[U], ext[U];
             // ---- conditioning network (fargan.py:139-160): R, K, R ----
-            fg_slice<WT, 48, 384, U, CPAD, 0>(w.cond(0), lds, FG_OFF(condin),
+            fg_slice<WS, 48, 384, U, CPAD, 0>(w.cond(0), lds, FG_OFF(condin),
                                            FG_OFF(condin), CPAD, g * 48, lds,
                                            tid, v);
             if (tid < 48) {
@@ -830,7 +855,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 for (int u = 0; u < U; ++u) L[u].c1[g * 48 + tid] = tanhf(v[u]);
             }
             __syncthreads();
-            fg_slice<WT, 384, 384, U, 48, 1>(w.k_cond1(g), lds,
+            fg_slice<WS, 384, 384, U, 48, 1>(w.k_cond1(g), lds,
                                           FG_OFF(c1) + g * 48,
                                           FG_OFF(c1) + g * 48, 48, 0, lds, tid, v);
             fg_exchange_sum<U, 384, 0>(c, v, v, lds, tid, tot, ext);
@@ -839,7 +864,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 for (int u = 0; u < U; ++u) L[u].c2[tid] = tanhf(tot[u]);
             }
             __syncthreads();
-            fg_slice<WT, 64, 512, U, CPAD, 1>(w.cond(2), lds, FG_OFF(c2), FG_OFF(c2),
+            fg_slice<WS, 64, 512, U, CPAD, 1>(w.cond(2), lds, FG_OFF(c2), FG_OFF(c2),
                                            CPAD, g * 64, lds, tid, v);
 #pragma unroll
             for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
@@ -894,13 +919,13 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 auto under_hh = [&](int n, auto pb) __attribute__((always_inline)) {
                     float unused[U];
                     const int hoff = FG_OFF(hid) + n * FG_HOP;
-                    fg_slice<WT, 96, 768, U, 256, decltype(pb)::value, true>(
+                    fg_slice<WI, 96, 768, U, 256, decltype(pb)::value, true>(
                         w.gru_hh(n), lds, hoff, hoff, 256, g * 96, lds, tid,
                         unused);
                 };
                 auto under_ih = [&](int n, auto pb) __attribute__((always_inline)) {
                     float unused[U];
-                    fg_slice<WT, 96, 768, U, 128, decltype(pb)::value, true>(
+                    fg_slice<WI, 96, 768, U, 128, decltype(pb)::value, true>(
                         w.gru_ih(n) + 256 * 768, lds, FG_OFF(skipbuf) + 1024,
                         FG_OFF(skipbuf) + 1024, 128, g * 96, lds, tid, unused);
                 };
@@ -921,7 +946,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 using PB3 = std::integral_constant<int, 3>;
 
                 // ---- framewise conv (R) + its GLU gate (K): 1 exchange ----
-                fg_slice<WT, 32, 256, U, 520, 0>(w.fwconv(), lds, FG_OFF(subin),
+                fg_slice<WS, 32, 256, U, 520, 0>(w.fwconv(), lds, FG_OFF(subin),
                                               FG_OFF(subin), 520, g * 32, lds,
                                               tid, v);
                 FG_STAMP(1);
@@ -931,7 +956,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     if (tid < 32) L[u].own[tid] = m[u];
                 }
                 __syncthreads();
-                fg_slice<WT, 256, 256, U, 32, 1>(
+                fg_slice<WI, 256, 256, U, 32, 1>(
                     w.k_fwconv_glu(g), lds, FG_OFF(own),
                     FG_OFF(own), 32, 0, lds, tid, v);
                 FG_STAMP(2);
@@ -965,16 +990,16 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     // this member's 32 units x 3 gates = packed rows g*96 ..
                     float gi[U];
                     if constexpr (LVL >= 2)
-                        fg_slice<WT, 96, 768, U, 256, 1>(
+                        fg_slice<WI, 96, 768, U, 256, 1>(
                             w.gru_ih(n), lds, xa, xa, 256, g * 96, lds, tid, gi);
                     else
-                        fg_slice<WT, 96, 768, U, 384, 1>(
+                        fg_slice<WI, 96, 768, U, 384, 1>(
                             w.gru_ih(n), lds, xa, FG_OFF(skipbuf) + 1024, 256,
                             g * 96, lds, tid, gi);
                     if constexpr (LVL == 0) {
                         float ghv[U];
                         const int hoff = FG_OFF(hid) + n * FG_HOP;
-                        fg_slice<WT, 96, 768, U, 256, 0>(
+                        fg_slice<WI, 96, 768, U, 256, 0>(
                             w.gru_hh(n), lds, hoff, hoff, 256, g * 96, lds, tid,
                             ghv);
                         if (tid < 96) {
@@ -1007,7 +1032,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     }
                     __syncthreads();
                     FG_STAMP(5 + 4 * n);
-                    fg_slice<WT, 256, 256, U, 32, 1>(
+                    fg_slice<WI, 256, 256, U, 32, 1>(
                         w.k_gru_glu(n, g), lds, FG_OFF(own),
                         FG_OFF(own), 32, 0, lds, tid, v);
                     FG_STAMP(6 + 4 * n);
@@ -1023,7 +1048,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                             c, v, m, lds, tid, tot, ext, [&]() {
                                 under_ih(2, PB2{});
                                 float unused[U];
-                                fg_slice<WT, 32, 256, U, 384, 3, true>(
+                                fg_slice<WS, 32, 256, U, 384, 3, true>(
                                     w.skip() + 768 * 256, lds,
                                     FG_OFF(skipbuf) + 768, FG_OFF(skipbuf) + 768,
                                     384, g * 32, lds, tid, unused);
@@ -1040,7 +1065,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                         fg_exchange_sum<U, 256, 32>(
                             c, v, m, lds, tid, tot, ext, [&]() {
                                 float unused[U];
-                                fg_slice<WT, 32, 256, U, 512, 2, true>(
+                                fg_slice<WS, 32, 256, U, 512, 2, true>(
                                     w.skip(), lds, FG_OFF(skipbuf),
                                     FG_OFF(skipbuf), 512, g * 32, lds, tid,
                                     unused);
@@ -1074,11 +1099,11 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 // ---- skip dense (R): vector exchange ----
                 FG_STAMP(16);
                 if constexpr (LVL >= 2)   // (only the last GRU's columns are left)
-                    fg_slice<WT, 32, 256, U, 256, 1>(
+                    fg_slice<WS, 32, 256, U, 256, 1>(
                         w.skip() + 512 * 256, lds, FG_OFF(skipbuf) + 512,
                         FG_OFF(skipbuf) + 512, 256, g * 32, lds, tid, v);
                 else
-                    fg_slice<WT, 32, 256, U, FG_SKIP, 1>(
+                    fg_slice<WS, 32, 256, U, FG_SKIP, 1>(
                         w.skip(), lds, FG_OFF(skipbuf), FG_OFF(skipbuf), FG_SKIP,
                         g * 32, lds, tid, v);
                 FG_STAMP(17);
@@ -1095,7 +1120,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 FG_STAMP(18);
                 // ---- skip GLU (R) + output layer (K): 1 exchange ----
-                fg_slice<WT, 32, 256, U, 256, 0>(w.skip_glu(), lds, FG_OFF(f1), FG_OFF(f1),
+                fg_slice<WI, 32, 256, U, 256, 0>(w.skip_glu(), lds, FG_OFF(f1), FG_OFF(f1),
                                               256, g * 32, lds, tid, v);
                 if (tid < 32) {
 #pragma unroll
@@ -1104,7 +1129,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 __syncthreads();
                 FG_STAMP(19);
-                fg_slice<WT, 64, 64, U, 32, 1>(w.k_out(g), lds,
+                fg_slice<WS, 64, 64, U, 32, 1>(w.k_out(g), lds,
                                             FG_OFF(own), FG_OFF(own), 32, 0, lds,
                                             tid, v);
                 FG_STAMP(20);

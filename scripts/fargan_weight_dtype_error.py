@@ -9,7 +9,7 @@ inputs = oracle.synthetic_inputs(32, 861, seed=55)
 pick = [3, 30, 11, 20]
 with torch.inference_mode():
     want = oracle.fargan_generator_forward(*[t[pick] for t in inputs], state)
-for dtype in ('fp32', 'f16'):
+for dtype in ('fp32', 'mixed', 'f16'):
     promonet_amd.configure(MODEL='fargan', FARGAN_WEIGHT_DTYPE=dtype)
     model = promonet_amd.model.Generator(); model.load_state_dict(state); model = model.to(device).eval()
     with torch.inference_mode():

@@ -16,7 +16,7 @@ from bench import synthetic_inputs  # noqa: E402
 repeats = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 device = torch.device('cuda:0')
 bad = 0
-for dtype in ('fp32', 'f16'):
+for dtype in ('fp32', 'mixed', 'f16'):
     promonet_amd.configure(MODEL='fargan', FARGAN_WEIGHT_DTYPE=dtype)
     torch.manual_seed(0)
     model = promonet_amd.model.Generator().to(device).eval()

@@ -8,8 +8,9 @@ from util import max_abs
 
 pytestmark = pytest.mark.gpu
 
-# fp32 math everywhere; f16 only changes the STORAGE of the streamed weights
-GATE = {'fp32': 5e-6, 'f16': 1e-2}
+# fp32 math everywhere; f16 / mixed only change the STORAGE of the streamed
+# weights ('mixed': GRU cells and GLU gates f16, the other layers fp32)
+GATE = {'fp32': 5e-6, 'f16': 1e-2, 'mixed': 3e-5}
 
 
 @pytest.fixture()
@@ -39,7 +40,7 @@ def on(device, inputs):
 
 
 @pytest.mark.parametrize('mode', [1, 2])
-@pytest.mark.parametrize('dtype', ['fp32', 'f16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'f16', 'mixed'])
 def test_matches_reference_golden(
     device, golden_fargan, fargan_model, dtype, mode
 ):
@@ -95,7 +96,15 @@ def test_long_sequence_vs_oracle(device, fargan_model):
     assert max_abs(got, want) < 2e-5
 
 
-@pytest.mark.parametrize('dtype,mode', [('fp32', 1), ('fp32', 2), ('f16', 2)])
+# whole-utterance max-abs gates: the north star's 1e-4, and for the mixed
+# storage 3x what it measures (6e-6 on the CPU emulation of its rounding,
+# scripts/fargan_weight_sensitivity.py)
+FULL_GATE = {'fp32': 1e-4, 'f16': 1e-4, 'mixed': 2e-5}
+
+
+@pytest.mark.parametrize(
+    'dtype,mode',
+    [('fp32', 1), ('fp32', 2), ('f16', 2), ('mixed', 2), ('mixed', 1)])
 def test_full_size_config5(device, fargan_model, dtype, mode):
     """BASELINE.json configs[4] at full size: batch 32 x 861 frames (3 444
     dependent sub-frame steps - where autoregressive drift would show).
@@ -118,7 +127,7 @@ def test_full_size_config5(device, fargan_model, dtype, mode):
     tail = max_abs(got[pick][..., -256 * 40:], want[..., -256 * 40:])
     print(f'fargan full size {dtype} mode {mode}: max-abs {error:.3e} (last 40 '
           f'frames {tail:.3e}; abs-max {want.abs().max().item():.3f})')
-    assert error < 1e-4
+    assert error < FULL_GATE[dtype]
 
 
 def test_module_seam(device, fargan_model):
