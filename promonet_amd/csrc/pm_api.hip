@@ -2162,7 +2162,9 @@ static int fargan_launch(
         const int groups = (a.B + U - 1) / U;
         ca.nclusters = groups < resident ? groups : resident;
         const dim3 grid(ca.nclusters * FG_G), block(FG_THREADS);
-        const size_t smem = (size_t)U * sizeof(FgLds);
+        // (+ the LDS-resident short slices of a one-utterance cluster)
+        const size_t smem = (size_t)U * sizeof(FgLds) +
+                            (U == 1 ? FgResident<WT, 1>::BYTES : 0);
         auto launch = [&](auto kern) -> hipError_t {
             hipError_t e = pm_ensure_dynamic_lds(
                 reinterpret_cast<const void*>(kern), (int)smem);

@@ -741,6 +741,42 @@ __device__ __forceinline__ void fg_slice(
     fg_slice_sum<RW, U, PB>(lds, tid, sum);
 }
 
+// LDS-resident copies of a member's SHORT slices (one utterance per cluster,
+// 2-byte insensitive type, i.e. 'mixed' and f16 storage): the five GLU-gate
+// slices, the output layer's K slice and the last-GRU columns of the skip dense
+// layer are 8 .. 32 KB each, so what they cost per step is not their bytes but
+// one exposed L2 round trip apiece on the dependency chain (0.5 - 1.0 us of the
+// 24 us step each, profiles/r03/fargan/timeline_fargan.txt). 120 KB ('mixed')
+// beside the 37.5 KB of recurrent state: copied once per launch, read with
+// ds_read_b128 ever after. Same packing, rows compacted to the member's own;
+// the (row, K-slice) -> thread map and the summation order do not change, so
+// the audio is bit-identical to the streamed form.
+template <class WT, int U>
+struct FgResident {
+    typedef typename FgTypes<WT>::S S;
+    typedef typename FgTypes<WT>::I I;
+    static constexpr bool ON = U == 1 && sizeof(I) == 2;
+    static constexpr size_t FWGLU = 0;                                    // (256 x 32) I
+    static constexpr size_t GRUGLU = FWGLU + 256 * 32 * sizeof(I);        // 3 x (256 x 32) I
+    static constexpr size_t SKIPGLU = GRUGLU + 3 * 256 * 32 * sizeof(I);  // (32 x 256) I
+    static constexpr size_t OUT = SKIPGLU + 32 * 256 * sizeof(I);         // (64 x 32) S
+    static constexpr size_t SKIP3 = OUT + 64 * 32 * sizeof(S);            // (32 x 256) S
+    static constexpr size_t BYTES = ON ? SKIP3 + 32 * 256 * sizeof(S) : 0;
+};
+
+// rows r0 .. r0 + RW of a [KPAD / VEC][RPAD][VEC]-packed matrix -> LDS
+// [KPAD / VEC][RW][VEC] (`src` points at row r0 of block 0)
+template <class T, int RW, int RPAD, int KPAD>
+__device__ __forceinline__ void fg_pin(char* dst, const T* src, int tid) {
+    constexpr int VEC = FgVec<T>::VEC;
+    constexpr int UNITS = KPAD / VEC * RW;      // 16-byte pieces
+    for (int i = tid; i < UNITS; i += FG_THREADS) {
+        const int b = i / RW, r = i % RW;
+        reinterpret_cast<uint4*>(dst)[i] = *reinterpret_cast<const uint4*>(
+            src + ((size_t)b * RPAD + r) * VEC);
+    }
+}
+
 struct FarganClusterArgs {
     FarganArgs f;
     unsigned* state;      // per cluster: FG_CSTATE words of granules
@@ -781,6 +817,23 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
     const int cluster = blockIdx.x / FG_G;
     const int T = a.T;
     const int nin = a.nfeat + a.G;
+    typedef FgResident<WT, U> RES;
+    char* const res = reinterpret_cast<char*>(lds) + U * sizeof(FgLds);
+    if constexpr (RES::ON) {
+        fg_pin<WI, 256, 256, 32>(res + RES::FWGLU, w.k_fwconv_glu(g), tid);
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            fg_pin<WI, 256, 256, 32>(
+                res + RES::GRUGLU + n * 256 * 32 * sizeof(WI), w.k_gru_glu(n, g),
+                tid);
+        fg_pin<WI, 32, 256, 256>(
+            res + RES::SKIPGLU, w.skip_glu() + g * 32 * FgVec<WI>::VEC, tid);
+        fg_pin<WS, 64, 64, 32>(res + RES::OUT, w.k_out(g), tid);
+        fg_pin<WS, 32, 256, 256>(
+            res + RES::SKIP3,
+            w.skip() + 512 * 256 + g * 32 * FgVec<WS>::VEC, tid);
+        // (the first barrier of the utterance loop orders these writes)
+    }
     FgCluster c;
     c.buf = reinterpret_cast<unsigned long long*>(
         ca.state + (size_t)cluster * FG_CSTATE);
@@ -957,8 +1010,9 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 __syncthreads();
                 fg_slice<WI, 256, 256, U, 32, 1>(
-                    w.k_fwconv_glu(g), lds, FG_OFF(own),
-                    FG_OFF(own), 32, 0, lds, tid, v);
+                    RES::ON ? reinterpret_cast<const WI*>(res + RES::FWGLU)
+                            : w.k_fwconv_glu(g),
+                    lds, FG_OFF(own), FG_OFF(own), 32, 0, lds, tid, v);
                 FG_STAMP(2);
                 if constexpr (LVL >= 2) {
                     fg_exchange_sum<U, 256, 32>(
@@ -1033,8 +1087,11 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     __syncthreads();
                     FG_STAMP(5 + 4 * n);
                     fg_slice<WI, 256, 256, U, 32, 1>(
-                        w.k_gru_glu(n, g), lds, FG_OFF(own),
-                        FG_OFF(own), 32, 0, lds, tid, v);
+                        RES::ON ? reinterpret_cast<const WI*>(
+                                      res + RES::GRUGLU +
+                                      n * 256 * 32 * sizeof(WI))
+                                : w.k_gru_glu(n, g),
+                        lds, FG_OFF(own), FG_OFF(own), 32, 0, lds, tid, v);
                     FG_STAMP(6 + 4 * n);
                     if (LVL >= 2 && n == 0) {
                         fg_exchange_sum<U, 256, 32>(
@@ -1098,7 +1155,12 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
 
                 // ---- skip dense (R): vector exchange ----
                 FG_STAMP(16);
-                if constexpr (LVL >= 2)   // (only the last GRU's columns are left)
+                if constexpr (LVL >= 2 && RES::ON)
+                    fg_slice<WS, 32, 32, U, 256, 1>(
+                        reinterpret_cast<const WS*>(res + RES::SKIP3), lds,
+                        FG_OFF(skipbuf) + 512, FG_OFF(skipbuf) + 512, 256, 0,
+                        lds, tid, v);
+                else if constexpr (LVL >= 2)   // (only the last GRU's columns are left)
                     fg_slice<WS, 32, 256, U, 256, 1>(
                         w.skip() + 512 * 256, lds, FG_OFF(skipbuf) + 512,
                         FG_OFF(skipbuf) + 512, 256, g * 32, lds, tid, v);
@@ -1120,8 +1182,14 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 FG_STAMP(18);
                 // ---- skip GLU (R) + output layer (K): 1 exchange ----
-                fg_slice<WI, 32, 256, U, 256, 0>(w.skip_glu(), lds, FG_OFF(f1), FG_OFF(f1),
-                                              256, g * 32, lds, tid, v);
+                if constexpr (RES::ON)
+                    fg_slice<WI, 32, 32, U, 256, 0>(
+                        reinterpret_cast<const WI*>(res + RES::SKIPGLU), lds,
+                        FG_OFF(f1), FG_OFF(f1), 256, 0, lds, tid, v);
+                else
+                    fg_slice<WI, 32, 256, U, 256, 0>(
+                        w.skip_glu(), lds, FG_OFF(f1), FG_OFF(f1), 256, g * 32,
+                        lds, tid, v);
                 if (tid < 32) {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
@@ -1129,9 +1197,10 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 __syncthreads();
                 FG_STAMP(19);
-                fg_slice<WS, 64, 64, U, 32, 1>(w.k_out(g), lds,
-                                            FG_OFF(own), FG_OFF(own), 32, 0, lds,
-                                            tid, v);
+                fg_slice<WS, 64, 64, U, 32, 1>(
+                    RES::ON ? reinterpret_cast<const WS*>(res + RES::OUT)
+                            : w.k_out(g),
+                    lds, FG_OFF(own), FG_OFF(own), 32, 0, lds, tid, v);
                 FG_STAMP(20);
                 if constexpr (LVL >= 2) {
                     fg_exchange_sum<U, 64, 0>(c, v, v, lds, tid, tot, ext,
