@@ -16,7 +16,9 @@ Every function cites the reference file:line it follows (paths relative to
   `librosa.A_weighting` (third-party `librosa`, unpinned, `setup.py:17`):
   PARITY UNPINNED. Neither package is installed or vendored; the functions
   below restate their published algorithms and are anchored on the
-  reference's call sites only.
+  reference's call sites only. Second sources (tests/test_cpu_oracle.py):
+  numpy.quantile, scipy.signal.freqs + the IEC 61672 table, and
+  transformers.audio_utils (mel filter bank, STFT, amplitude_to_db).
 
 All math is fp32 on CPU (`torch` ATen), the same op sequence the reference
 executes: un-fused conv1d / conv_transpose1d / leaky_relu / add.
