@@ -44,7 +44,10 @@ FARGAN_FLOP_PER_SAMPLE = 73_843
 # FARGAN weights read per dependent sub-frame step (fargan.py:199-335): framewise
 # conv 256x520 + its GLU 256x256, 3 x (GRU 768x384 + 768x256 + GLU 256x256),
 # skip 256x1152 + GLU, output 64x256; + 1/4 of the per-frame conditioning net
-FARGAN_WEIGHTS = 2_246_656 + (2 * 371 * 371 + 512 * 371) // 4
+FARGAN_STEP_WEIGHTS = 2_246_656
+# (with f16 storage only: the fp32 / mixed modes run the conditioning network
+# for every frame as three GEMMs ahead of the recurrence, pm_fargan_cond_kernel)
+FARGAN_COND_WEIGHTS = 2 * 371 * 371 + 512 * 371
 # of those: 3 x (768 x 384 + 768 x 256) GRU + 5 x 256 x 256 GLU gate weights
 FARGAN_MIXED_F16_WEIGHTS = 3 * 768 * 640 + 5 * 256 * 256
 # dense MFMA peaks per USEFUL flop (f16x3: three MFMAs per product)
@@ -655,10 +658,17 @@ def main():
             steps = frames * 4
             # ('mixed': the GRU cells and the GLU gates - 1 802 240 of the
             # weights a sub-frame step streams - are stored f16, the rest fp32)
+            storage = promonet_amd.FARGAN_WEIGHT_DTYPE
             wbytes = {
-                'f16': FARGAN_WEIGHTS * 2,
-                'mixed': FARGAN_WEIGHTS * 4 - FARGAN_MIXED_F16_WEIGHTS * 2,
-            }.get(promonet_amd.FARGAN_WEIGHT_DTYPE, FARGAN_WEIGHTS * 4)
+                'f16': (FARGAN_STEP_WEIGHTS + FARGAN_COND_WEIGHTS // 4) * 2,
+                'mixed': FARGAN_STEP_WEIGHTS * 4 - FARGAN_MIXED_F16_WEIGHTS * 2,
+            }.get(storage, FARGAN_STEP_WEIGHTS * 4)
+            # a one-utterance cluster member keeps its seven short slices in
+            # the LDS (FgResident, pm_fargan.h: 2-byte gate storage): those are
+            # not streamed from the L2
+            resident = args.batch <= 32 and storage in ('mixed', 'f16')
+            if resident:
+                wbytes -= 8 * {'mixed': 122_880, 'f16': 102_400}[storage]
             # compulsory HBM bytes of one launch: features in, audio out, the
             # weights once (they stay L2-resident for all 3 444 steps)
             hbm_bytes = args.batch * frames * (128 * 4 + 256 * 4) + wbytes
@@ -678,7 +688,10 @@ def main():
             # least: two barriers, an LDS reduction, one L2 round trip) and 6
             # tagged-granule exchanges (1.3 us for a vector, 2.3 us for 8 x 256
             # partial sums) - profiles/r02/timeline_fargan_ticks_x10.txt
-            floor_us = 13 * 1.1 + 2 * 1.3 + 4 * 2.3
+            # (a slice read out of the LDS-resident copies has no L2 round
+            # trip: 0.6 us for its barriers and reduction)
+            floor_us = (6 * 1.1 + 7 * .6 if resident else 13 * 1.1) + \
+                2 * 1.3 + 4 * 2.3
             result['roofline'] = {
                 'kernel': 'pm_fargan_cluster_kernel',
                 # (not an HBM fraction: `achieved` / `peak` / `frac` are the L2

@@ -2129,10 +2129,16 @@ static size_t fargan_state_bytes() {
     return align256((size_t)FG_MAX_CLUSTERS * FG_CSTATE * 4 + 256);
 }
 
+// (B * T, 512) conditioning vectors of pm_fargan_cond_kernel: fp32-stored
+// conditioning weights only (f16 storage keeps them inside the cluster kernel)
+static size_t fargan_precond_bytes(pm_fargan_t h, int B, int T) {
+    return h->dtype == PM_F16 ? 0 : align256((size_t)B * T * 512 * sizeof(float));
+}
+
 extern "C" size_t pm_fargan_workspace_bytes(pm_fargan_t h, int B, int T) {
     if (!h || B < 1 || T < 1) return 0;
     return align256((size_t)B * T * pad32(h->nfeat + 1) * sizeof(float)) +
-           fargan_state_bytes();
+           fargan_state_bytes() + fargan_precond_bytes(h, B, T);
 }
 
 template <class WT>
@@ -2149,6 +2155,30 @@ static int fargan_launch(
         ca.f = a;
         ca.state = (unsigned*)cluster_state;
         ca.error = ca.state + (size_t)FG_MAX_CLUSTERS * FG_CSTATE;
+        ca.precond = nullptr;
+        if constexpr (std::is_same<typename FarganWeights<WT>::S, float>::value) {
+            // the conditioning network of every frame, ahead of the walk
+            FarganCondArgs cn;
+            cn.features_cl = a.features_cl; cn.global = a.global;
+            cn.cond = (float*)((char*)cluster_state + fargan_state_bytes());
+            cn.B = a.B; cn.T = a.T; cn.cstride = a.cstride; cn.nfeat = a.nfeat;
+            cn.G = a.G; cn.global_batch = a.global_batch;
+            const size_t cond_lds =
+                (size_t)FG_CN * (FG_CPITCH + FG_OPITCH) * sizeof(float);
+            hipError_t ce = pm_ensure_dynamic_lds(
+                reinterpret_cast<const void*>(pm_fargan_cond_kernel),
+                (int)cond_lds);
+            HIP_TRY(ce);
+            const long long frames = (long long)a.B * a.T;
+            hipLaunchKernelGGL(
+                pm_fargan_cond_kernel,
+                dim3((unsigned)((frames + FG_CN - 1) / FG_CN)), dim3(256),
+                cond_lds, s, cn, w.base + FarganWeights<WT>::COND0,
+                w.base + FarganWeights<WT>::COND1,
+                w.base + FarganWeights<WT>::COND2);
+            HIP_TRY(hipGetLastError());
+            ca.precond = cn.cond;
+        }
 #ifdef PM_TUNING
         ca.timeline = g_timeline;
 #endif

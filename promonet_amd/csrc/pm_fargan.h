@@ -380,6 +380,114 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
 
 
 // ===========================================================================
+// The conditioning network is NOT part of the recurrence (fargan.py:139-160: three
+// bias-free Linear + tanh over a frame's 113 features + 258 global channels;
+// nothing generated feeds back into it): for fp32-stored conditioning weights
+// ('fp32' / 'mixed' storage) the cluster kernel takes it for every frame of the
+// batch from ONE launch ahead of the utterance walk - three chained GEMMs over
+// B x T independent frames on the exact-fp32 matrix unit (v_mfma_f32_32x32x2_f32)
+// - instead of three weight slices and two inter-workgroup exchanges per frame.
+// A workgroup owns 32 frames: input and hidden rows stay in LDS, the weights
+// are read as they are already packed for the mat-vec kernels ([k / 4][row][4]
+// fp32: a lane's float4 = one row, 4 consecutive k - the A operand of four
+// MFMAs whose k pairs are (j, 4 + j) of an 8-wide K group). A frame's result
+// depends on that frame alone, so it is the same bits whatever batch it is in.
+// ===========================================================================
+#define FG_CN 32            // frames per workgroup
+#define FG_CPITCH 388       // LDS row pitch (floats) of a <= 384-wide operand
+#define FG_OPITCH 516       // ... of the 512-wide result (16 B x odd: no conflicts)
+
+struct FarganCondArgs {
+    const float* features_cl;   // (B, T, cstride)
+    const float* global;        // (Bg, G)
+    float* cond;                // (B * T, 512)
+    int B, T, cstride, nfeat, G, global_batch;
+};
+
+// out[f][row] = tanh(sum_k W[row][k] in[f][k]) for the workgroup's 32 frames;
+// `in` has 376 valid (zero-padded) columns; 4 waves x MT M-tiles = ROWS rows
+template <int ROWS, int OPITCH>
+__device__ __forceinline__ void fg_cond_layer(
+    const float* __restrict__ w, const float* in, float* out, int tid) {
+    constexpr int MT = ROWS / 32 / 4;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    floatx16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const float* wp = w + ((size_t)h * ROWS + wave * MT * 32 + r) * 4;
+    const float* bp = in + r * FG_CPITCH + 4 * h;
+#pragma unroll 2
+    for (int q = 0; q < 376 / 8; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(bp + 8 * q);
+        float4 a[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            a[i] = *reinterpret_cast<const float4*>(
+                wp + ((size_t)2 * q * ROWS + i * 32) * 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b.w, acc[i], 0, 0, 0);
+        }
+    }
+    // C/D layout: column (frame) = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float4 v;
+            v.x = tanhf(acc[i][4 * g4]);     v.y = tanhf(acc[i][4 * g4 + 1]);
+            v.z = tanhf(acc[i][4 * g4 + 2]); v.w = tanhf(acc[i][4 * g4 + 3]);
+            *reinterpret_cast<float4*>(
+                out + r * OPITCH + (wave * MT + i) * 32 + 8 * g4 + 4 * h) = v;
+        }
+}
+
+__global__ __launch_bounds__(256) void pm_fargan_cond_kernel(
+    FarganCondArgs a, const float* __restrict__ w0,
+    const float* __restrict__ w1, const float* __restrict__ w2) {
+    extern __shared__ __attribute__((aligned(16))) float cl[];
+    float* bufa = cl;                          // [32][FG_CPITCH]
+    float* bufb = cl + FG_CN * FG_CPITCH;      // [32][FG_OPITCH]
+    const int tid = threadIdx.x;
+    const long long total = (long long)a.B * a.T;
+    const long long f0 = (long long)blockIdx.x * FG_CN;
+    const int nin = a.nfeat + a.G;
+    // the frames' inputs [features | global | zeros] (a frame past the end of
+    // the batch reads as zeros; its result is not stored)
+    for (int i = tid; i < FG_CN * 376; i += 256) {
+        const int f = i / 376, k = i % 376;
+        const long long frame = f0 + f;
+        float v = 0.f;
+        if (frame < total && k < nin) {
+            const int b = (int)(frame / a.T);
+            v = k < a.nfeat
+                ? a.features_cl[(size_t)frame * a.cstride + k]
+                : a.global[(size_t)(a.global_batch == 1 ? 0 : b) * a.G +
+                           (k - a.nfeat)];
+        }
+        bufa[f * FG_CPITCH + k] = v;
+    }
+    __syncthreads();
+    fg_cond_layer<384, FG_CPITCH>(w0, bufa, bufb, tid);    // padded rows: tanh(0)
+    __syncthreads();
+    fg_cond_layer<384, FG_CPITCH>(w1, bufb, bufa, tid);
+    __syncthreads();
+    fg_cond_layer<512, FG_OPITCH>(w2, bufa, bufb, tid);
+    __syncthreads();
+    for (int i = tid; i < FG_CN * 128; i += 256) {
+        const int f = i / 128, q = i % 128;
+        if (f0 + f < total)
+            reinterpret_cast<float4*>(a.cond + (size_t)(f0 + f) * 512)[q] =
+                *reinterpret_cast<const float4*>(bufb + f * FG_OPITCH + 4 * q);
+    }
+}
+
+// ===========================================================================
 // Cluster variant: FG_G = 8 workgroups cooperate on one utterance.
 //
 // One CU streams the 9.2 MB of weights at ~45 GB/s: 213 us per sub-frame step.
@@ -782,6 +890,8 @@ struct FarganClusterArgs {
     unsigned* state;      // per cluster: FG_CSTATE words of granules
     unsigned* error;
     int nclusters;
+    const float* precond;   // (B * T, 512) from pm_fargan_cond_kernel (fp32-
+                            // stored conditioning weights), or null
 #ifdef PM_TUNING
     unsigned long long* timeline;   // debug: phase stamps of one sub-frame step
 #endif
@@ -899,6 +1009,17 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
             }
             __syncthreads();
             float v[U], m[U], tot[U], ext[U];
+            if constexpr (std::is_same<WS, float>::value) {
+                // ---- conditioning network: computed for every frame by
+                // pm_fargan_cond_kernel ahead of this launch ----
+                if (tid < 512) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        L[u].cond[tid] =
+                            ca.precond[((size_t)ut[u] * T + t) * 512 + tid];
+                }
+                __syncthreads();
+            } else {
             // ---- conditioning network (fargan.py:139-160): R, K, R ----
             fg_slice<WS, 48, 384, U, CPAD, 0>(w.cond(0), lds, FG_OFF(condin),
                                            FG_OFF(condin), CPAD, g * 48, lds,
@@ -922,6 +1043,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
 #pragma unroll
             for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
             fg_exchange<U, 64>(c, m, lds, FG_OFF(cond), tid);
+            }
 
 #pragma unroll 1
             for (int s = 0; s < 4; ++s) {
