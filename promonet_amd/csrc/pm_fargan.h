@@ -1093,6 +1093,13 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 constexpr int LVL = FG_UNDER(WT);
                 auto under_hh = [&](int n, auto pb) __attribute__((always_inline)) {
                     float unused[U];
+                    // (opaque thread id again: without it this slice's weight
+                    // addresses are computed ahead of the exchange and the
+                    // kernel sits at the 168-register limit of 768 threads;
+                    // with it 69 - and 3-4 % faster, profiles/r04/ab_fargan_tail.txt;
+                    // all-f16 storage measured 1-2 % slower that way and keeps
+                    // the hoisted form)
+                    if constexpr (sizeof(WS) == 4) asm volatile("" : "+v"(tid));
                     const int hoff = FG_OFF(hid) + n * FG_HOP;
                     fg_slice<WI, 96, 768, U, 256, decltype(pb)::value, true>(
                         w.gru_hh(n), lds, hoff, hoff, 256, g * 96, lds, tid,
