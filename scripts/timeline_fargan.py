@@ -12,7 +12,10 @@ from promonet_amd import _lib  # noqa: E402
 from bench import synthetic_inputs  # noqa: E402
 
 device = torch.device('cuda:0')
-promonet_amd.configure(MODEL='fargan')
+import os  # noqa: E402
+promonet_amd.configure(
+    MODEL='fargan',
+    FARGAN_WEIGHT_DTYPE=os.environ.get('FARGAN_WEIGHT_DTYPE', 'fp32'))
 torch.manual_seed(0)
 model = promonet_amd.model.Generator().to(device).eval()
 lib = _lib.lib()
