@@ -662,7 +662,9 @@ __device__ __forceinline__ void fg_exchange(
 // every member), ext[u] = element tid of the gathered vector.
 // Q = FG_THREADS / R threads share the 8 polls of a row; their partial
 // totals meet in LDS (field `part`, which the caller's fg_slice is done with).
-template <int U, int R, int E, class Under = FgNoOverlap>
+// PAIRED: `part` comes from fg_slice_pair - row 32 w + l sits in lane l < 32 of
+// wave w - instead of row tid in thread tid.
+template <int U, int R, int E, bool PAIRED = false, class Under = FgNoOverlap>
 __device__ __forceinline__ void fg_exchange_sum(
     FgCluster& c, const float (&part)[U], const float (&extra)[U], float* lds,
     int tid, float (&total)[U], float (&ext)[U], Under under = Under()) {
@@ -672,11 +674,12 @@ __device__ __forceinline__ void fg_exchange_sum(
     static_assert(QN * NG >= FG_G && R + E <= FG_SLOTS, "exchange geometry");
     c.epoch += 1u;
     const unsigned epoch = c.epoch;
-    if (tid < R) {
+    if (PAIRED ? ((tid & 32) == 0 && (tid >> 6) < R / 32) : tid < R) {
+        const int prow = PAIRED ? (tid >> 6) * 32 + (tid & 31) : tid;
 #pragma unroll
         for (int u = 0; u < U; ++u)
             __hip_atomic_store(
-                fg_granule(c, epoch, u, c.g, tid),
+                fg_granule(c, epoch, u, c.g, prow),
                 ((unsigned long long)epoch << 32) | __float_as_uint(part[u]),
                 FG_RLX);
     }
@@ -847,6 +850,50 @@ __device__ __forceinline__ void fg_slice(
     if constexpr (DEFER) return;
     __syncthreads();
     fg_slice_sum<RW, U, PB>(lds, tid, sum);
+}
+
+// A K-split layer on the member's own 32 inputs, all R rows (GLU gates, the
+// output layer): 12 K-values a thread, three partial sums a row through LDS
+// and a barrier is what fg_slice makes of it - here the two half-waves of
+// wave w share rows 32 w .. 32 w + 31 (lanes 0-31 the first 16 inputs, lanes
+// 32-63 the other 16) and ONE v_permlane32_swap adds the halves: no LDS
+// reduction, no barrier. sum[u] is valid in lanes 0-31 of waves < R / 32
+// (row 32 w + lane): fg_exchange_sum<..., PAIRED> publishes from there.
+template <class WT, int R, int U>
+__device__ __forceinline__ void fg_slice_pair(
+    const WT* __restrict__ w, const float* lds, int x, int tid,
+    float (&sum)[U]) {
+    constexpr int VEC = FgVec<WT>::VEC;
+    constexpr int HB = 16 / VEC;             // 16-byte blocks per half
+    if constexpr (U >= 2) asm volatile("" : "+v"(tid));   // (as fg_slice)
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5;
+    float acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.f;
+    if (wave < R / 32) {
+        const WT* wp =
+            w + ((size_t)half * HB * R + wave * 32 + (lane & 31)) * VEC;
+        uint4 wv[HB];
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+            wv[i] = *reinterpret_cast<const uint4*>(wp + (size_t)i * R * VEC);
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            float wf[VEC];
+            FgVec<WT>::unpack(wv[i], wf);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                acc[u] += FgVec<WT>::dotf(
+                    wf, lds + u * FG_LSTRIDE + x + (half * HB + i) * VEC);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned bits = __float_as_uint(acc[u]);
+        // [1] in lanes 0-31 = the upper half-wave's value of the same row
+        const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+        sum[u] = acc[u] + __uint_as_float(sw[1]);
+    }
 }
 
 // LDS-resident copies of a member's SHORT slices (one utterance per cluster,
@@ -1099,7 +1146,8 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     // with it 69 - and 3-4 % faster, profiles/r04/ab_fargan_tail.txt;
                     // all-f16 storage measured 1-2 % slower that way and keeps
                     // the hoisted form)
-                    if constexpr (sizeof(WS) == 4) asm volatile("" : "+v"(tid));
+                    if constexpr (sizeof(WS) == 4 || U > 1)
+                        asm volatile("" : "+v"(tid));
                     const int hoff = FG_OFF(hid) + n * FG_HOP;
                     fg_slice<WI, 96, 768, U, 256, decltype(pb)::value, true>(
                         w.gru_hh(n), lds, hoff, hoff, 256, g * 96, lds, tid,
@@ -1138,24 +1186,24 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     if (tid < 32) L[u].own[tid] = m[u];
                 }
                 __syncthreads();
-                fg_slice<WI, 256, 256, U, 32, 1>(
+                fg_slice_pair<WI, 256, U>(
                     RES::ON ? reinterpret_cast<const WI*>(res + RES::FWGLU)
                             : w.k_fwconv_glu(g),
-                    lds, FG_OFF(own), FG_OFF(own), 32, 0, lds, tid, v);
+                    lds, FG_OFF(own), tid, v);
                 FG_STAMP(2);
                 if constexpr (LVL >= 2) {
-                    fg_exchange_sum<U, 256, 32>(
+                    fg_exchange_sum<U, 256, 32, true>(
                         c, v, m, lds, tid, tot, ext, [&]() {
                             under_ih(0, PB2{}); under_ih(1, PB3{}); });
                     collect96(1, 0, PB2{});
                     collect96(1, 1, PB3{});
                 } else if constexpr (LVL == 1) {
-                    fg_exchange_sum<U, 256, 32>(
+                    fg_exchange_sum<U, 256, 32, true>(
                         c, v, m, lds, tid, tot, ext,
                         [&]() { under_hh(0, PB2{}); });
                     collect96(0, 0, PB2{});
                 } else {
-                    fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                    fg_exchange_sum<U, 256, 32, true>(c, v, m, lds, tid, tot, ext);
                 }
                 FG_STAMP(3);
                 if (tid < 256) {
@@ -1215,22 +1263,22 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     }
                     __syncthreads();
                     FG_STAMP(5 + 4 * n);
-                    fg_slice<WI, 256, 256, U, 32, 1>(
+                    fg_slice_pair<WI, 256, U>(
                         RES::ON ? reinterpret_cast<const WI*>(
                                       res + RES::GRUGLU +
                                       n * 256 * 32 * sizeof(WI))
                                 : w.k_gru_glu(n, g),
-                        lds, FG_OFF(own), FG_OFF(own), 32, 0, lds, tid, v);
+                        lds, FG_OFF(own), tid, v);
                     FG_STAMP(6 + 4 * n);
                     if (LVL >= 2 && n == 0) {
-                        fg_exchange_sum<U, 256, 32>(
+                        fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext,
                             [&]() { under_hh(2, PB2{}); });
                         collect96(0, 2, PB2{});
                     } else if (LVL >= 2 && n == 1) {
                         // skip dense layer (fargan.py:317-322), columns
                         // [fwconv | lookback | previous]: known since E1
-                        fg_exchange_sum<U, 256, 32>(
+                        fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext, [&]() {
                                 under_ih(2, PB2{});
                                 float unused[U];
@@ -1248,7 +1296,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                         }
                     } else if (LVL >= 2) {
                         // ... and columns [g0 | g1]
-                        fg_exchange_sum<U, 256, 32>(
+                        fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext, [&]() {
                                 float unused[U];
                                 fg_slice<WS, 32, 256, U, 512, 2, true>(
@@ -1263,12 +1311,12 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                             for (int u = 0; u < U; ++u) L[u].skpre[tid] += sa[u];
                         }
                     } else if (LVL == 1 && n < 2) {
-                        fg_exchange_sum<U, 256, 32>(
+                        fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext,
                             [&]() { under_hh(n + 1, PB2{}); });
                         collect96(0, n + 1, PB2{});
                     } else {
-                        fg_exchange_sum<U, 256, 32>(c, v, m, lds, tid, tot, ext);
+                        fg_exchange_sum<U, 256, 32, true>(c, v, m, lds, tid, tot, ext);
                     }
                     FG_STAMP(7 + 4 * n);
                     if (tid < 256) {
@@ -1326,17 +1374,17 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 __syncthreads();
                 FG_STAMP(19);
-                fg_slice<WS, 64, 64, U, 32, 1>(
+                fg_slice_pair<WS, 64, U>(
                     RES::ON ? reinterpret_cast<const WS*>(res + RES::OUT)
                             : w.k_out(g),
-                    lds, FG_OFF(own), FG_OFF(own), 32, 0, lds, tid, v);
+                    lds, FG_OFF(own), tid, v);
                 FG_STAMP(20);
                 if constexpr (LVL >= 2) {
-                    fg_exchange_sum<U, 64, 0>(c, v, v, lds, tid, tot, ext,
+                    fg_exchange_sum<U, 64, 0, true>(c, v, v, lds, tid, tot, ext,
                                               [&]() { under_hh(1, PB2{}); });
                     collect96(0, 1, PB2{});
                 } else {
-                    fg_exchange_sum<U, 64, 0>(c, v, v, lds, tid, tot, ext);
+                    fg_exchange_sum<U, 64, 0, true>(c, v, v, lds, tid, tot, ext);
                 }
                 FG_STAMP(21);
 #pragma unroll
