@@ -618,6 +618,19 @@ __device__ __forceinline__ void fg_poll(
             val[u][i] = __uint_as_float((unsigned)v[u][i]);
 }
 
+// Lane map of the slices reduced inside a wave (fg_slice_lanes below): LPR lanes
+// a row, 64 / LPR rows a wave, rows fastest; lane j = 0 of a row leads
+template <int LPR>
+struct FgLanes {
+    static constexpr int RPW = 64 / LPR;
+    __device__ static __forceinline__ int row(int tid) {
+        return (tid >> 6) * RPW + (tid & (RPW - 1));
+    }
+    __device__ static __forceinline__ bool lead(int tid, int rows) {
+        return (tid & 63) < RPW && row(tid) < rows;
+    }
+};
+
 // Vector exchange: `mine[u]` (valid for tid < N) = element g N + tid of
 // utterance u's 8 N-long vector; on return field `dst` of every utterance's
 // FgLds holds the whole vector in every member's LDS. Callers guarantee (a
@@ -625,17 +638,25 @@ __device__ __forceinline__ void fg_poll(
 // `under` runs between the publish and the poll: work that does not depend on
 // the exchanged data (a slice of the NEXT layers' products of the previous
 // step's state) streams its weights while the granules travel.
-template <int U, int N, class Under = FgNoOverlap>
+// PUB > 0: `mine` comes out of fg_slice_lanes<..., PUB> (element r in the lead
+// lane of row r) instead of thread r.
+template <int U, int N, int PUB = 0, class Under = FgNoOverlap>
 __device__ __forceinline__ void fg_exchange(
     FgCluster& c, const float (&mine)[U], float* lds, int dst, int tid,
     Under under = Under()) {
     c.epoch += 1u;
     const unsigned epoch = c.epoch;
-    if (tid < N) {
+    bool pub = tid < N;
+    int slot = tid;
+    if constexpr (PUB > 0) {
+        pub = FgLanes<PUB>::lead(tid, N);
+        slot = FgLanes<PUB>::row(tid);
+    }
+    if (pub) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
             __hip_atomic_store(
-                fg_granule(c, epoch, u, c.g, tid),
+                fg_granule(c, epoch, u, c.g, slot),
                 ((unsigned long long)epoch << 32) | __float_as_uint(mine[u]),
                 FG_RLX);
     }
@@ -850,6 +871,86 @@ __device__ __forceinline__ void fg_slice(
     if constexpr (DEFER) return;
     __syncthreads();
     fg_slice_sum<RW, U, PB>(lds, tid, sum);
+}
+
+// ---------------------------------------------------------------------------
+// Slices reduced INSIDE a wave (round 4). fg_slice hands every (row, K-part) to
+// one thread and lets the parts of a row meet in LDS behind a barrier: ~500
+// cycles a slice, 13 slices a step. Here the LPR lanes that share a row sit in
+// ONE wave - lane = j * RPW + r with RPW = 64 / LPR rows a wave, rows fastest, so
+// a load instruction still reads RPW consecutive rows (16 B each) of LPR
+// different K blocks - and add up with row_ror DPP steps and the two gfx950
+// half-wave / quarter-wave swaps: no LDS, no barrier. Lane j = 0 of a row
+// ("lead") carries the result on.
+// ---------------------------------------------------------------------------
+// sum of `v` over the LPR lanes of a row; every lane of the row gets the same
+// bits (each step adds the same two partial sums in either order)
+template <int LPR>
+__device__ __forceinline__ float fg_lane_sum(float v, int tid) {
+    static_assert(LPR == 8 || LPR == 16, "lanes per row");
+    // lane bits: LPR 8 -> j = bits 3-5; LPR 16 -> j = bits 2-5
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(
+        0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));        // row_ror:8
+    if constexpr (LPR == 16)
+        v += __uint_as_float(__builtin_amdgcn_update_dpp(
+            0u, __float_as_uint(v), 0x124, 0xf, 0xf, false));    // row_ror:4
+    {
+        const unsigned b = __float_as_uint(v);
+        const auto sw = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+        v += __uint_as_float((tid & 16) ? sw[0] : sw[1]);
+    }
+    {
+        const unsigned b = __float_as_uint(v);
+        const auto sw = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+        v += __uint_as_float((tid & 32) ? sw[0] : sw[1]);
+    }
+    return v;
+}
+
+// RW rows of y_u = W x_u; `w` points at the first of them in K block 0 of a
+// [k / VEC][...][VEC] packing whose K blocks are BSTRIDE elements apart (RPAD *
+// VEC for the streamed matrices, RW * VEC for an LDS-resident copy). Lane j of a
+// row takes K blocks j, j + LPR, ... (x: [0, split) from LDS field xa, the rest
+// from xb). sum[u]: the row's product in every lane of the row.
+template <class WT, int RW, int BSTRIDE, int U, int KPAD, int LPR>
+__device__ __forceinline__ void fg_slice_lanes(
+    const WT* __restrict__ w, const float* lds, int xa, int xb, int split,
+    int tid, float (&sum)[U]) {
+    if constexpr (U >= 2) asm volatile("" : "+v"(tid));   // (as fg_slice)
+    constexpr int VEC = FgVec<WT>::VEC;
+    constexpr int BLOCKS = KPAD / VEC;
+    constexpr int NB = (BLOCKS + LPR - 1) / LPR;
+    constexpr int RPW = 64 / LPR;
+    static_assert(RW % RPW == 0 && RW * LPR <= FG_THREADS, "slice geometry");
+    const int lane = tid & 63, j = lane / RPW;
+    const int row = (tid >> 6) * RPW + lane % RPW;
+    float acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.f;
+    if (row < RW) {                                   // (whole waves)
+        const int sb = split / VEC;
+        const WT* wp = w + (size_t)j * BSTRIDE + row * VEC;
+        uint4 wv[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            wv[i] = i * LPR + j < BLOCKS
+                ? *reinterpret_cast<const uint4*>(wp + (size_t)i * LPR * BSTRIDE)
+                : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int b = i * LPR + j;
+            if (b < BLOCKS) {
+                float wf[VEC];
+                FgVec<WT>::unpack(wv[i], wf);
+                const int off = b < sb ? xa + b * VEC : xb + (b - sb) * VEC;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    acc[u] += FgVec<WT>::dotf(wf, lds + u * FG_LSTRIDE + off);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) sum[u] = fg_lane_sum<LPR>(acc[u], tid);
 }
 
 // A K-split layer on the member's own 32 inputs, all R rows (GLU gates, the
@@ -1176,16 +1277,20 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 using PB3 = std::integral_constant<int, 3>;
 
                 // ---- framewise conv (R) + its GLU gate (K): 1 exchange ----
-                fg_slice<WS, 32, 256, U, 520, 0>(w.fwconv(), lds, FG_OFF(subin),
-                                              FG_OFF(subin), 520, g * 32, lds,
-                                              tid, v);
+                fg_slice_lanes<WS, 32, 256 * FgVec<WS>::VEC, U, 520, 16>(
+                    w.fwconv() + g * 32 * FgVec<WS>::VEC, lds, FG_OFF(subin),
+                    FG_OFF(subin), 520, tid, v);
                 FG_STAMP(1);
+                if (FgLanes<16>::lead(tid, 32)) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    m[u] = tanhf(v[u]);
-                    if (tid < 32) L[u].own[tid] = m[u];
+                    for (int u = 0; u < U; ++u)
+                        L[u].own[FgLanes<16>::row(tid)] = tanhf(v[u]);
                 }
                 __syncthreads();
+                // (the member's slice travels with the partial sums below)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    m[u] = tid < 32 ? L[u].own[tid] : 0.f;
                 fg_slice_pair<WI, 256, U>(
                     RES::ON ? reinterpret_cast<const WI*>(res + RES::FWGLU)
                             : w.k_fwconv_glu(g),
@@ -1221,12 +1326,13 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     // this member's 32 units x 3 gates = packed rows g*96 ..
                     float gi[U];
                     if constexpr (LVL >= 2)
-                        fg_slice<WI, 96, 768, U, 256, 1>(
-                            w.gru_ih(n), lds, xa, xa, 256, g * 96, lds, tid, gi);
+                        fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 256, 8>(
+                            w.gru_ih(n) + g * 96 * FgVec<WI>::VEC, lds, xa, xa,
+                            256, tid, gi);
                     else
-                        fg_slice<WI, 96, 768, U, 384, 1>(
-                            w.gru_ih(n), lds, xa, FG_OFF(skipbuf) + 1024, 256,
-                            g * 96, lds, tid, gi);
+                        fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 384, 8>(
+                            w.gru_ih(n) + g * 96 * FgVec<WI>::VEC, lds, xa,
+                            FG_OFF(skipbuf) + 1024, 256, tid, gi);
                     if constexpr (LVL == 0) {
                         float ghv[U];
                         const int hoff = FG_OFF(hid) + n * FG_HOP;
@@ -1239,13 +1345,17 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                         }
                     }
                     FG_STAMP(4 + 4 * n);
+                    if (FgLanes<8>::lead(tid, 96)) {
+                        const int row = FgLanes<8>::row(tid);
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            L[u].part2[row] = LVL >= 2
+                                ? gi[u] + L[u].gil[n][row] : gi[u];
+                    }
                     if (tid < 96) {
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            L[u].part2[tid] = LVL >= 2
-                                ? gi[u] + L[u].gil[n][tid] : gi[u];
+                        for (int u = 0; u < U; ++u)
                             L[u].part2[96 + tid] = L[u].gh[n][tid];
-                        }
                     }
                     __syncthreads();
 #pragma unroll
@@ -1333,44 +1443,49 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 // ---- skip dense (R): vector exchange ----
                 FG_STAMP(16);
                 if constexpr (LVL >= 2 && RES::ON)
-                    fg_slice<WS, 32, 32, U, 256, 1>(
+                    fg_slice_lanes<WS, 32, 32 * FgVec<WS>::VEC, U, 256, 8>(
                         reinterpret_cast<const WS*>(res + RES::SKIP3), lds,
-                        FG_OFF(skipbuf) + 512, FG_OFF(skipbuf) + 512, 256, 0,
-                        lds, tid, v);
+                        FG_OFF(skipbuf) + 512, FG_OFF(skipbuf) + 512, 256, tid,
+                        v);
                 else if constexpr (LVL >= 2)   // (only the last GRU's columns are left)
-                    fg_slice<WS, 32, 256, U, 256, 1>(
-                        w.skip() + 512 * 256, lds, FG_OFF(skipbuf) + 512,
-                        FG_OFF(skipbuf) + 512, 256, g * 32, lds, tid, v);
+                    fg_slice_lanes<WS, 32, 256 * FgVec<WS>::VEC, U, 256, 8>(
+                        w.skip() + 512 * 256 + g * 32 * FgVec<WS>::VEC, lds,
+                        FG_OFF(skipbuf) + 512, FG_OFF(skipbuf) + 512, 256, tid,
+                        v);
                 else
-                    fg_slice<WS, 32, 256, U, FG_SKIP, 1>(
-                        w.skip(), lds, FG_OFF(skipbuf), FG_OFF(skipbuf), FG_SKIP,
-                        g * 32, lds, tid, v);
+                    fg_slice_lanes<WS, 32, 256 * FgVec<WS>::VEC, U, FG_SKIP, 8>(
+                        w.skip() + g * 32 * FgVec<WS>::VEC, lds, FG_OFF(skipbuf),
+                        FG_OFF(skipbuf), FG_SKIP, tid, v);
                 FG_STAMP(17);
+                {
+                    const int row = FgLanes<8>::row(tid) & 31;
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    m[u] = tanhf(LVL >= 2
-                        ? v[u] + (tid < 32 ? L[u].skpre[tid] : 0.f) : v[u]);
+                    for (int u = 0; u < U; ++u)
+                        m[u] = tanhf(LVL >= 2 ? v[u] + L[u].skpre[row] : v[u]);
+                }
                 if constexpr (LVL >= 2) {
-                    fg_exchange<U, 32>(c, m, lds, FG_OFF(f1), tid,
-                                       [&]() { under_hh(0, PB2{}); });
+                    fg_exchange<U, 32, 8>(c, m, lds, FG_OFF(f1), tid,
+                                          [&]() { under_hh(0, PB2{}); });
                     collect96(0, 0, PB2{});
                 } else {
-                    fg_exchange<U, 32>(c, m, lds, FG_OFF(f1), tid);
+                    fg_exchange<U, 32, 8>(c, m, lds, FG_OFF(f1), tid);
                 }
                 FG_STAMP(18);
                 // ---- skip GLU (R) + output layer (K): 1 exchange ----
                 if constexpr (RES::ON)
-                    fg_slice<WI, 32, 32, U, 256, 0>(
+                    fg_slice_lanes<WI, 32, 32 * FgVec<WI>::VEC, U, 256, 8>(
                         reinterpret_cast<const WI*>(res + RES::SKIPGLU), lds,
-                        FG_OFF(f1), FG_OFF(f1), 256, 0, lds, tid, v);
+                        FG_OFF(f1), FG_OFF(f1), 256, tid, v);
                 else
-                    fg_slice<WI, 32, 256, U, 256, 0>(
-                        w.skip_glu(), lds, FG_OFF(f1), FG_OFF(f1), 256, g * 32,
-                        lds, tid, v);
-                if (tid < 32) {
+                    fg_slice_lanes<WI, 32, 256 * FgVec<WI>::VEC, U, 256, 8>(
+                        w.skip_glu() + g * 32 * FgVec<WI>::VEC, lds, FG_OFF(f1),
+                        FG_OFF(f1), 256, tid, v);
+                if (FgLanes<8>::lead(tid, 32)) {
+                    const int row = FgLanes<8>::row(tid);
 #pragma unroll
                     for (int u = 0; u < U; ++u)
-                        L[u].own[tid] = L[u].f1[g * 32 + tid] * fg_sigmoid(v[u]);
+                        L[u].own[row] =
+                            L[u].f1[g * 32 + row] * fg_sigmoid(v[u]);
                 }
                 __syncthreads();
                 FG_STAMP(19);
