@@ -1250,28 +1250,35 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     if constexpr (sizeof(WS) == 4 || U > 1)
                         asm volatile("" : "+v"(tid));
                     const int hoff = FG_OFF(hid) + n * FG_HOP;
-                    fg_slice<WI, 96, 768, U, 256, decltype(pb)::value, true>(
-                        w.gru_hh(n), lds, hoff, hoff, 256, g * 96, lds, tid,
-                        unused);
+                    // (reduced inside the wave too: the lead lane of a row
+                    // writes gh[n] itself - nobody reads it before the
+                    // exchange's barrier - so there is nothing to collect)
+                    fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 256, 8>(
+                        w.gru_hh(n) + g * 96 * FgVec<WI>::VEC, lds, hoff, hoff,
+                        256, tid, unused);
+                    if (FgLanes<8>::lead(tid, 96)) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            L[u].gh[n][FgLanes<8>::row(tid)] = unused[u];
+                    }
                 };
                 auto under_ih = [&](int n, auto pb) __attribute__((always_inline)) {
                     float unused[U];
-                    fg_slice<WI, 96, 768, U, 128, decltype(pb)::value, true>(
-                        w.gru_ih(n) + 256 * 768, lds, FG_OFF(skipbuf) + 1024,
-                        FG_OFF(skipbuf) + 1024, 128, g * 96, lds, tid, unused);
+                    fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 128, 8>(
+                        w.gru_ih(n) + 256 * 768 + g * 96 * FgVec<WI>::VEC, lds,
+                        FG_OFF(skipbuf) + 1024, FG_OFF(skipbuf) + 1024, 128, tid,
+                        unused);
+                    if (FgLanes<8>::lead(tid, 96)) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            L[u].gil[n][FgLanes<8>::row(tid)] = unused[u];
+                    }
                 };
                 // which 0: -> gh[n] (W_hh h), 1: -> gil[n] (W_ih lookback part)
                 auto collect96 = [&](int which, int n, auto pb)
                     __attribute__((always_inline)) {
-                    float sv[U];
-                    fg_slice_sum<96, U, decltype(pb)::value>(lds, tid, sv);
-                    if (tid < 96) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            if (which == 0) L[u].gh[n][tid] = sv[u];
-                            else L[u].gil[n][tid] = sv[u];
-                        }
-                    }
+                    // (nothing left to do: see under_hh)
+                    (void)which; (void)n; (void)pb;
                 };
                 using PB2 = std::integral_constant<int, 2>;
                 using PB3 = std::integral_constant<int, 3>;
@@ -1391,35 +1398,38 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                         fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext, [&]() {
                                 under_ih(2, PB2{});
-                                float unused[U];
-                                fg_slice<WS, 32, 256, U, 384, 3, true>(
-                                    w.skip() + 768 * 256, lds,
-                                    FG_OFF(skipbuf) + 768, FG_OFF(skipbuf) + 768,
-                                    384, g * 32, lds, tid, unused);
+                                float sb[U];
+                                fg_slice_lanes<WS, 32, 256 * FgVec<WS>::VEC, U,
+                                               384, 16>(
+                                    w.skip() + 768 * 256 +
+                                        g * 32 * FgVec<WS>::VEC,
+                                    lds, FG_OFF(skipbuf) + 768,
+                                    FG_OFF(skipbuf) + 768, 384, tid, sb);
+                                if (FgLanes<16>::lead(tid, 32)) {
+#pragma unroll
+                                    for (int u = 0; u < U; ++u)
+                                        L[u].skpre[FgLanes<16>::row(tid)] = sb[u];
+                                }
                             });
                         collect96(1, 2, PB2{});
-                        float sb[U];
-                        fg_slice_sum<32, U, 3>(lds, tid, sb);
-                        if (tid < 32) {
-#pragma unroll
-                            for (int u = 0; u < U; ++u) L[u].skpre[tid] = sb[u];
-                        }
                     } else if (LVL >= 2) {
                         // ... and columns [g0 | g1]
                         fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext, [&]() {
-                                float unused[U];
-                                fg_slice<WS, 32, 256, U, 512, 2, true>(
-                                    w.skip(), lds, FG_OFF(skipbuf),
-                                    FG_OFF(skipbuf), 512, g * 32, lds, tid,
-                                    unused);
-                            });
-                        float sa[U];
-                        fg_slice_sum<32, U, 2>(lds, tid, sa);
-                        if (tid < 32) {
+                                // (the same lead lanes as under E3: a
+                                // read-modify-write of their own element)
+                                float sa[U];
+                                fg_slice_lanes<WS, 32, 256 * FgVec<WS>::VEC, U,
+                                               512, 16>(
+                                    w.skip() + g * 32 * FgVec<WS>::VEC, lds,
+                                    FG_OFF(skipbuf), FG_OFF(skipbuf), 512, tid,
+                                    sa);
+                                if (FgLanes<16>::lead(tid, 32)) {
 #pragma unroll
-                            for (int u = 0; u < U; ++u) L[u].skpre[tid] += sa[u];
-                        }
+                                    for (int u = 0; u < U; ++u)
+                                        L[u].skpre[FgLanes<16>::row(tid)] += sa[u];
+                                }
+                            });
                     } else if (LVL == 1 && n < 2) {
                         fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext,
