@@ -681,18 +681,14 @@ __device__ __forceinline__ void fg_exchange(
 // sums (the gated activation itself). On return, for tid < R: total[u] = the
 // sum over members 0..7, in that order, of row tid's partials (identical in
 // every member), ext[u] = element tid of the gathered vector.
-// Q = FG_THREADS / R threads share the 8 polls of a row; their partial
-// totals meet in LDS (field `part`, which the caller's fg_slice is done with).
+// Thread `row` polls all eight members' granules of its row itself.
 // PAIRED: `part` comes from fg_slice_pair - row 32 w + l sits in lane l < 32 of
 // wave w - instead of row tid in thread tid.
 template <int U, int R, int E, bool PAIRED = false, class Under = FgNoOverlap>
 __device__ __forceinline__ void fg_exchange_sum(
     FgCluster& c, const float (&part)[U], const float (&extra)[U], float* lds,
     int tid, float (&total)[U], float (&ext)[U], Under under = Under()) {
-    constexpr int Q = FG_THREADS / R;          // 3 (R 256), 2 (384), 12 (64)
-    constexpr int QN = Q > FG_G ? FG_G : Q;    // polling threads per row
-    constexpr int NG = (FG_G + QN - 1) / QN;   // granules per polling thread
-    static_assert(QN * NG >= FG_G && R + E <= FG_SLOTS, "exchange geometry");
+    static_assert(R + E <= FG_SLOTS && R <= FG_THREADS, "exchange geometry");
     c.epoch += 1u;
     const unsigned epoch = c.epoch;
     if (PAIRED ? ((tid & 32) == 0 && (tid >> 6) < R / 32) : tid < R) {
@@ -713,53 +709,46 @@ __device__ __forceinline__ void fg_exchange_sum(
                 FG_RLX);
     }
     under();
-    const int row = tid % R, q = tid / R;
-    if (q < QN) {
-        // members q NG .. q NG + NG - 1 (clamped: a duplicate poll of member
-        // 7 is masked out of the sum below)
-        unsigned long long* src[U][NG];
-        float val[U][NG];
+    // Thread `row` polls all 8 members' granules of its row (and its element of
+    // the vector that travels with them) in ONE loop and adds them in member
+    // order: the same bits in every member, no partial totals through LDS and
+    // no barrier of the exchange's own - the caller's next barrier (there is
+    // at least one between two exchanges, which also keeps the two payload
+    // buffers apart) orders whatever `under` left in LDS. What a caller writes to
+    // LDS between this exchange and that barrier must not be anything `under`
+    // READS (a wave may still be inside `under` when another has its totals):
+    // the step keeps them apart - every under-slice reads state vectors /
+    // skip columns other than the ones the exchange's consumer writes.
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) { total[u] = 0.f; ext[u] = 0.f; }
+    if (tid < R) {
+        // (four utterances in lockstep: four rounds of two members - the
+        // registers of 36 granules in flight are not there; same order)
+        constexpr int CH = U >= 4 ? 2 : FG_G;
 #pragma unroll
-            for (int i = 0; i < NG; ++i) {
-                const int m = q * NG + i;
-                src[u][i] = fg_granule(c, epoch, u, m < FG_G ? m : FG_G - 1, row);
+        for (int m0 = 0; m0 < FG_G; m0 += CH) {
+            constexpr int XE = E > 0 ? 1 : 0;
+            const bool last = m0 + CH == FG_G;
+            unsigned long long* src[U][CH + XE];
+            float val[U][CH + XE];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    src[u][i] = fg_granule(c, epoch, u, m0 + i, tid);
+                if constexpr (E > 0)   // (polled in every round: one loop shape)
+                    src[u][CH] = fg_granule(c, epoch, u, tid / (E > 0 ? E : 1),
+                                            R + tid % (E > 0 ? E : 1));
             }
-        fg_poll<U, NG>(c, epoch, src, val);
+            fg_poll<U, CH + XE>(c, epoch, src, val);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float sum = 0.f;
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int i = 0; i < NG; ++i)
-                if (q * NG + i < FG_G) sum += val[u][i];
-            lds[u * FG_LSTRIDE + FG_OFF(part) + tid] = sum;
+                for (int i = 0; i < CH; ++i) total[u] += val[u][i];
+                if constexpr (E > 0) { if (last) ext[u] = val[u][CH]; }
+            }
         }
     }
-    if (E > 0 && tid < R) {
-        unsigned long long* src[U][1];
-        float val[U][1];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            src[u][0] = fg_granule(c, epoch, u, tid / (E > 0 ? E : 1),
-                                   R + tid % (E > 0 ? E : 1));
-        fg_poll<U, 1>(c, epoch, src, val);
-#pragma unroll
-        for (int u = 0; u < U; ++u) ext[u] = val[u][0];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        float t = 0.f;
-        if (tid < R) {
-#pragma unroll
-            for (int k = 0; k < QN; ++k)
-                t += lds[u * FG_LSTRIDE + FG_OFF(part) + tid + k * R];
-        }
-        total[u] = t;
-    }
-    // no trailing barrier: the next writer of buffer P is at least one
-    // barrier away (see fg_slice)
 }
 
 // RW rows (r0 .. r0 + RW of a matrix packed with RPAD rows) of y_u = W x_u
