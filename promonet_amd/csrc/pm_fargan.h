@@ -216,9 +216,28 @@ struct FarganArgs {
                                 // simply stops early; its tail is zero-filled
 };
 
+// The activations sit on the dependency chain of every step (12 of them, one
+// after the other): libm's expf + IEEE division are ~40 dependent instructions
+// a sigmoid, tanhf ~80 - 250-500 cycles each at one wave's issue rate. Here the
+// same formulas on the transcendental unit (v_exp_f32, v_rcp_f32: 1 ulp each,
+// 4-6 instructions): absolute error ~1e-7, i.e. fp32 rounding of an O(1)
+// value; what it does to the audio is measured (tests/test_gpu_fargan.py).
+#ifndef FG_EXACT_ACTIVATIONS
+__device__ __forceinline__ float fg_sigmoid(float v) {
+    return __builtin_amdgcn_rcpf(
+        1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+__device__ __forceinline__ float fg_tanh(float v) {
+    // 1 - 2 / (1 + e^(2 v)); e^(2 v) = inf / 0 at the ends gives +1 / -1
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(
+        1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
+}
+#else
 __device__ __forceinline__ float fg_sigmoid(float v) {
     return 1.f / (1.f + expf(-v));
 }
+__device__ __forceinline__ float fg_tanh(float v) { return tanhf(v); }
+#endif
 
 template <class WT>
 __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
@@ -273,14 +292,14 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
         {
             part[tid] = fg_gemv<WS, 384, 2>(w.cond(0), condin, condin, CPAD, CPAD, tid);
             __syncthreads();
-            if (tid < nin) c1[tid] = tanhf(part[tid] + part[tid + 384]);
+            if (tid < nin) c1[tid] = fg_tanh(part[tid] + part[tid + 384]);
             __syncthreads();
             part[tid] = fg_gemv<WS, 384, 2>(w.cond(1), c1, c1, CPAD, CPAD, tid);
             __syncthreads();
-            if (tid < nin) c2[tid] = tanhf(part[tid] + part[tid + 384]);
+            if (tid < nin) c2[tid] = fg_tanh(part[tid] + part[tid + 384]);
             __syncthreads();
             if (tid < 512)
-                cond[tid] = tanhf(fg_gemv<WS, 512, 1>(w.cond(2), c2, c2, CPAD, CPAD, tid));
+                cond[tid] = fg_tanh(fg_gemv<WS, 512, 1>(w.cond(2), c2, c2, CPAD, CPAD, tid));
             __syncthreads();
         }
         const int period = s_period;
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
             // ---- framewise conv: Linear(520 -> 256), tanh, GLU (:349-372) ----
             part[tid] = fg_gemv<WS, 256, 3>(w.fwconv(), subin, subin, 520, 520, tid);
             __syncthreads();
-            if (tid < 256) f1[tid] = tanhf(part[tid] + part[tid + 256] + part[tid + 512]);
+            if (tid < 256) f1[tid] = fg_tanh(part[tid] + part[tid + 256] + part[tid + 512]);
             __syncthreads();
             part[tid] = fg_gemv<WI, 256, 3>(w.fwconv_glu(), f1, f1, 256, 256, tid);
             __syncthreads();
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
                     const int in_ = fg_gru_row(2, tid);
                     const float r = fg_sigmoid(part[ir] + part2[ir]);
                     const float z = fg_sigmoid(part[iz] + part2[iz]);
-                    const float nn = tanhf(part[in_] + r * part2[in_]);
+                    const float nn = fg_tanh(part[in_] + r * part2[in_]);
                     hid[n][tid] = (1.f - z) * nn + z * hid[n][tid];
                 }
                 __syncthreads();
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
             // ---- skip connection + output layer (:317-333) ----
             part[tid] = fg_gemv<WS, 256, 3>(w.skip(), skipbuf, skipbuf, FG_SKIP, FG_SKIP, tid);
             __syncthreads();
-            if (tid < 256) f1[tid] = tanhf(part[tid] + part[tid + 256] + part[tid + 512]);
+            if (tid < 256) f1[tid] = fg_tanh(part[tid] + part[tid + 256] + part[tid + 512]);
             __syncthreads();
             part[tid] = fg_gemv<WI, 256, 3>(w.skip_glu(), f1, f1, 256, 256, tid);
             __syncthreads();
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_kernel(
                 float v = 0.f;
 #pragma unroll
                 for (int p = 0; p < 12; ++p) v += part[tid + 64 * p];
-                v = tanhf(v);
+                v = fg_tanh(v);
                 out[(size_t)t * FG_HOP + s * FG_SUB + tid] = v;
                 // the oldest 64 samples leave the window (fargan.py:122-129)
                 prev[(base + tid) & (FG_PREV - 1)] = v;
@@ -440,8 +459,8 @@ __device__ __forceinline__ void fg_cond_layer(
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             float4 v;
-            v.x = tanhf(acc[i][4 * g4]);     v.y = tanhf(acc[i][4 * g4 + 1]);
-            v.z = tanhf(acc[i][4 * g4 + 2]); v.w = tanhf(acc[i][4 * g4 + 3]);
+            v.x = fg_tanh(acc[i][4 * g4]);     v.y = fg_tanh(acc[i][4 * g4 + 1]);
+            v.z = fg_tanh(acc[i][4 * g4 + 2]); v.w = fg_tanh(acc[i][4 * g4 + 3]);
             *reinterpret_cast<float4*>(
                 out + r * OPITCH + (wave * MT + i) * 32 + 8 * g4 + 4 * h) = v;
         }
@@ -1163,7 +1182,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                                            tid, v);
             if (tid < 48) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) L[u].c1[g * 48 + tid] = tanhf(v[u]);
+                for (int u = 0; u < U; ++u) L[u].c1[g * 48 + tid] = fg_tanh(v[u]);
             }
             __syncthreads();
             fg_slice<WS, 384, 384, U, 48, 1>(w.k_cond1(g), lds,
@@ -1172,13 +1191,13 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
             fg_exchange_sum<U, 384, 0>(c, v, v, lds, tid, tot, ext);
             if (tid < 384) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) L[u].c2[tid] = tanhf(tot[u]);
+                for (int u = 0; u < U; ++u) L[u].c2[tid] = fg_tanh(tot[u]);
             }
             __syncthreads();
             fg_slice<WS, 64, 512, U, CPAD, 1>(w.cond(2), lds, FG_OFF(c2), FG_OFF(c2),
                                            CPAD, g * 64, lds, tid, v);
 #pragma unroll
-            for (int u = 0; u < U; ++u) m[u] = tanhf(v[u]);
+            for (int u = 0; u < U; ++u) m[u] = fg_tanh(v[u]);
             fg_exchange<U, 64>(c, m, lds, FG_OFF(cond), tid);
             }
 
@@ -1280,7 +1299,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 if (FgLanes<16>::lead(tid, 32)) {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
-                        L[u].own[FgLanes<16>::row(tid)] = tanhf(v[u]);
+                        L[u].own[FgLanes<16>::row(tid)] = fg_tanh(v[u]);
                 }
                 __syncthreads();
                 // (the member's slice travels with the partial sums below)
@@ -1361,7 +1380,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                             const float* p2 = L[u].part2;
                             const float r = fg_sigmoid(p2[tid] + p2[96 + tid]);
                             const float z = fg_sigmoid(p2[32 + tid] + p2[128 + tid]);
-                            const float nn = tanhf(p2[64 + tid] + r * p2[160 + tid]);
+                            const float nn = fg_tanh(p2[64 + tid] + r * p2[160 + tid]);
                             hnew = (1.f - z) * nn + z * L[u].hid[n][g * 32 + tid];
                             L[u].own[tid] = hnew;
                         }
@@ -1460,7 +1479,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     const int row = FgLanes<8>::row(tid) & 31;
 #pragma unroll
                     for (int u = 0; u < U; ++u)
-                        m[u] = tanhf(LVL >= 2 ? v[u] + L[u].skpre[row] : v[u]);
+                        m[u] = fg_tanh(LVL >= 2 ? v[u] + L[u].skpre[row] : v[u]);
                 }
                 if constexpr (LVL >= 2) {
                     fg_exchange<U, 32, 8>(c, m, lds, FG_OFF(f1), tid,
@@ -1505,7 +1524,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 for (int u = 0; u < U; ++u) {
                     FgLds& S = L[u];
                     if (tid < FG_SUB) {
-                        const float sample = tanhf(tot[u]);
+                        const float sample = fg_tanh(tot[u]);
                         if (tid / 8 == g && live[u] && t < len[u])
                             a.out[((size_t)ut[u] * T + t) * FG_HOP + s * FG_SUB +
                                   tid] = sample;
