@@ -684,19 +684,22 @@ def main():
             # stands beside it.
             l2_gbs = wbytes * steps * clusters / (avg_ms * 1e-3) / 1e9
             us_per_step = avg_ms * 1e3 / steps
-            # per sub-frame step: 13 matrix-slice phases (1.1 us each at
-            # least: two barriers, an LDS reduction, one L2 round trip) and 6
-            # tagged-granule exchanges (1.3 us for a vector, 2.3 us for 8 x 256
-            # partial sums) - profiles/r02/timeline_fargan_ticks_x10.txt
-            # (a slice read out of the LDS-resident copies has no L2 round
-            # trip: 0.6 us for its barriers and reduction)
-            floor_us = (6 * 1.1 + 7 * .6 if resident else 13 * 1.1) + \
-                2 * 1.3 + 4 * 2.3
+            # What a step is made of (phase timeline of this build,
+            # profiles/r04/fargan/timeline_fargan.txt: member 1 of cluster 0,
+            # one sub-frame step, shader-clock cycles): the six inter-workgroup
+            # exchanges - a write-through store and an sc1 load to the memory
+            # side of the L2s and back, with the known-early weight products
+            # streamed in between - are 57 % of it, the 13 matrix slices on
+            # the dependency chain (reduced inside a wave) and the activations
+            # the rest. The earlier rounds' "26 us latency floor" model (1.1
+            # us per slice for two barriers, an LDS reduction and an L2 round
+            # trip) described a step this build no longer runs.
+            exchange_share = 0.57
             result['roofline'] = {
                 'kernel': 'pm_fargan_cluster_kernel',
                 # (not an HBM fraction: `achieved` / `peak` / `frac` are the L2
                 # -> CU weight stream; the recurrence is latency-bound, see
-                # latency_model.frac_of_latency_floor)
+                # latency_model)
                 'bound': 'l2', 'level': 'l2 (weights re-streamed per step)',
                 'achieved': l2_gbs,
                 'peak': 34500., 'unit': 'GB/s',
@@ -714,8 +717,9 @@ def main():
                     'per_cu_l2_peak_gbs': 34500. / 256,
                     'exchanges_per_step': 6,
                     'matrix_slices_per_step': 13,
-                    'floor_us_per_step': floor_us,
-                    'frac_of_latency_floor': floor_us / us_per_step,
+                    'exchange_share_of_step': exchange_share,
+                    'exchange_share_source':
+                        'profiles/r04/fargan/timeline_fargan.txt',
                     'tflops': per_gpu * FARGAN_FLOP_PER_SAMPLE / 1e12}}
         else:
             # dominant kernel family: HIP events around its launches, on the

@@ -1,6 +1,7 @@
 """Phase timeline of one sub-frame step of the FARGAN cluster kernel (debug
-tool for a -DPM_TUNING build, GPU box): s_memtime stamps (100 MHz) of member 1
-of cluster 0 at frame 7, sub-frame 1."""
+tool for a -DPM_TUNING build, GPU box): s_memtime stamps of member 1 of
+cluster 0 at frame 7, sub-frame 1, in cycles of the shader clock (~2.1 GHz
+under this load; FARGAN_WEIGHT_DTYPE picks the weight storage)."""
 import sys
 from pathlib import Path
 
@@ -37,6 +38,11 @@ for batch in (32, 64):
     names.update({16: '-', 17: 'skip rows', 18: 'exchange vec',
                   19: 'skip_glu rows', 20: 'out cols', 21: 'exchange sum',
                   22: 'state update'})
-    print(f'batch {batch}: step total {(t[22] - t[0]) * 10} ns')
+    total = t[22] - t[0]
+    print(f'batch {batch}: step total {total} cycles')
+    exchanges = 0
     for i in range(1, 23):
-        print(f'  {names[i]:18s} {(t[i] - t[i - 1]) * 10:6d} ns')
+        print(f'  {names[i]:18s} {t[i] - t[i - 1]:6d} cycles')
+        if names[i].startswith('exchange'):
+            exchanges += t[i] - t[i - 1]
+    print(f'  exchanges: {exchanges} cycles = {exchanges / total:.2f} of the step')
