@@ -67,7 +67,7 @@ STEPS = 800000
 NUM_WORKERS = 10
 
 # Storage type of the streamed FARGAN weights (math is fp32): 'fp32', 'f16'
-# (6.7e-5 max-abs against the reference on random-init weights, over a 10 s
+# (6.6e-5 max-abs against the reference on random-init weights, over a 10 s
 # utterance) or 'mixed' - the GRU cells and the GLU gates (80 % of the stream,
 # all in front of a sigmoid / tanh) as f16, the conditioning network,
 # framewise conv, skip dense and output layer as fp32: 6e-6
