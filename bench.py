@@ -689,12 +689,12 @@ def main():
             # one sub-frame step, shader-clock cycles): the six inter-workgroup
             # exchanges - a write-through store and an sc1 load to the memory
             # side of the L2s and back, with the known-early weight products
-            # streamed in between - are 57 % of it, the 13 matrix slices on
+            # streamed in between - are 60 % of it, the 13 matrix slices on
             # the dependency chain (reduced inside a wave) and the activations
             # the rest. The earlier rounds' "26 us latency floor" model (1.1
             # us per slice for two barriers, an LDS reduction and an L2 round
             # trip) described a step this build no longer runs.
-            exchange_share = 0.57
+            exchange_share = 0.60
             result['roofline'] = {
                 'kernel': 'pm_fargan_cluster_kernel',
                 # (not an HBM fraction: `achieved` / `peak` / `frac` are the L2
