@@ -214,6 +214,16 @@ def test_fargan_engine_validation():
                                     ctypes.byref(handle)) == -1
     assert library.pm_fargan_create(113, 258, _lib.PM_BF16,
                                     ctypes.byref(handle)) == -1
+    # the mixed weight storage (GRU cells / GLU gates f16, the rest fp32):
+    # the Python table carries the header's constant
+    header = (ROOT / 'include' / 'promonet_hip.h').read_text()
+    mixed = int(re.search(r'#define PM_FARGAN_MIXED (\d+)', header).group(1))
+    assert _lib.DTYPES['mixed'] == mixed
+    assert library.pm_fargan_create(113, 258, mixed,
+                                    ctypes.byref(handle)) == 0
+    assert library.pm_fargan_destroy(handle) == 0
+    # ... and is not an MFMA operand type of the HiFi-GAN engine
+    assert mixed not in (_lib.PM_F32, _lib.PM_F16, _lib.PM_BF16, _lib.PM_F16X3)
 
 
 def test_patch_swaps_into_the_real_reference():
