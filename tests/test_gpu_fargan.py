@@ -65,13 +65,14 @@ def test_matches_reference_golden(
     model.model.kernel_mode = 0
 
 
-@pytest.mark.parametrize('batch', [37, 70, 135])
-def test_cluster_waves_and_determinism(device, fargan_model, batch):
+@pytest.mark.parametrize(
+    'batch,dtype', [(37, 'fp32'), (70, 'fp32'), (135, 'fp32'), (70, 'mixed')])
+def test_cluster_waves_and_determinism(device, fargan_model, batch, dtype):
     """More utterances than clusters: 2 (batch 37, one padded slot) or 4
     (batch 70, two padded slots) utterances advance in lockstep per cluster,
     and at 135 the 32 clusters walk a second wave with their epochs still
     counting. Repeated runs bit-identical, and the two kernels agree."""
-    model = fargan_model('fp32')
+    model = fargan_model(dtype)
     inputs = on(device, oracle.synthetic_inputs(batch, 6, seed=15))
     with torch.inference_mode():
         model.model.kernel_mode = 2
@@ -79,9 +80,14 @@ def test_cluster_waves_and_determinism(device, fargan_model, batch):
         again = model(*inputs, None)
         model.model.kernel_mode = 1
         single = model(*inputs, None)
+        model.model.kernel_mode = 2
+        alone = model(*[t[5:6] for t in inputs], None)
     model.model.kernel_mode = 0
     assert torch.equal(clustered, again)
     assert max_abs(clustered, single) < 2e-6
+    # a lockstep group's utterance == its stand-alone run (one utterance per
+    # cluster: LDS-resident short slices, eight-member polls in one round)
+    assert torch.equal(clustered[5], alone[0])
 
 
 def test_long_sequence_vs_oracle(device, fargan_model):
