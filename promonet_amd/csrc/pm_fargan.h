@@ -1019,13 +1019,23 @@ template <class WT, int U>
 struct FgResident {
     typedef typename FgTypes<WT>::S S;
     typedef typename FgTypes<WT>::I I;
-    static constexpr bool ON = U == 1 && sizeof(I) == 2;
+    static constexpr bool ON = U == 1;
+    // 2-byte gate storage: all seven (120 KB 'mixed', 100 KB f16); all-fp32
+    // storage (200 KB of them): the three GRU gates and the output layer,
+    // 104 KB - what fits beside the state
+    static constexpr bool ALL = ON && sizeof(I) == 2;
+    static constexpr bool ON_FWGLU = ALL, ON_SKIPGLU = ALL, ON_SKIP3 = ALL;
+    static constexpr bool ON_GRUGLU = ON, ON_OUT = ON;
     static constexpr size_t FWGLU = 0;                                    // (256 x 32) I
-    static constexpr size_t GRUGLU = FWGLU + 256 * 32 * sizeof(I);        // 3 x (256 x 32) I
+    static constexpr size_t GRUGLU =
+        FWGLU + (ON_FWGLU ? 256 * 32 * sizeof(I) : 0);                    // 3 x (256 x 32) I
     static constexpr size_t SKIPGLU = GRUGLU + 3 * 256 * 32 * sizeof(I);  // (32 x 256) I
-    static constexpr size_t OUT = SKIPGLU + 32 * 256 * sizeof(I);         // (64 x 32) S
+    static constexpr size_t OUT =
+        SKIPGLU + (ON_SKIPGLU ? 32 * 256 * sizeof(I) : 0);                // (64 x 32) S
     static constexpr size_t SKIP3 = OUT + 64 * 32 * sizeof(S);            // (32 x 256) S
-    static constexpr size_t BYTES = ON ? SKIP3 + 32 * 256 * sizeof(S) : 0;
+    static constexpr size_t BYTES =
+        ON ? SKIP3 + (ON_SKIP3 ? 32 * 256 * sizeof(S) : 0) : 0;
+    static_assert(BYTES + sizeof(FgLds) <= 160 * 1024, "LDS budget");
 };
 
 // rows r0 .. r0 + RW of a [KPAD / VEC][RPAD][VEC]-packed matrix -> LDS
@@ -1086,18 +1096,21 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
     typedef FgResident<WT, U> RES;
     char* const res = reinterpret_cast<char*>(lds) + U * sizeof(FgLds);
     if constexpr (RES::ON) {
-        fg_pin<WI, 256, 256, 32>(res + RES::FWGLU, w.k_fwconv_glu(g), tid);
+        if constexpr (RES::ON_FWGLU)
+            fg_pin<WI, 256, 256, 32>(res + RES::FWGLU, w.k_fwconv_glu(g), tid);
 #pragma unroll
         for (int n = 0; n < 3; ++n)
             fg_pin<WI, 256, 256, 32>(
                 res + RES::GRUGLU + n * 256 * 32 * sizeof(WI), w.k_gru_glu(n, g),
                 tid);
-        fg_pin<WI, 32, 256, 256>(
-            res + RES::SKIPGLU, w.skip_glu() + g * 32 * FgVec<WI>::VEC, tid);
+        if constexpr (RES::ON_SKIPGLU)
+            fg_pin<WI, 32, 256, 256>(
+                res + RES::SKIPGLU, w.skip_glu() + g * 32 * FgVec<WI>::VEC, tid);
         fg_pin<WS, 64, 64, 32>(res + RES::OUT, w.k_out(g), tid);
-        fg_pin<WS, 32, 256, 256>(
-            res + RES::SKIP3,
-            w.skip() + 512 * 256 + g * 32 * FgVec<WS>::VEC, tid);
+        if constexpr (RES::ON_SKIP3)
+            fg_pin<WS, 32, 256, 256>(
+                res + RES::SKIP3,
+                w.skip() + 512 * 256 + g * 32 * FgVec<WS>::VEC, tid);
         // (the first barrier of the utterance loop orders these writes)
     }
     FgCluster c;
@@ -1307,7 +1320,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 for (int u = 0; u < U; ++u)
                     m[u] = tid < 32 ? L[u].own[tid] : 0.f;
                 fg_slice_pair<WI, 256, U>(
-                    RES::ON ? reinterpret_cast<const WI*>(res + RES::FWGLU)
+                    RES::ON_FWGLU ? reinterpret_cast<const WI*>(res + RES::FWGLU)
                             : w.k_fwconv_glu(g),
                     lds, FG_OFF(own), tid, v);
                 FG_STAMP(2);
@@ -1389,7 +1402,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     __syncthreads();
                     FG_STAMP(5 + 4 * n);
                     fg_slice_pair<WI, 256, U>(
-                        RES::ON ? reinterpret_cast<const WI*>(
+                        RES::ON_GRUGLU ? reinterpret_cast<const WI*>(
                                       res + RES::GRUGLU +
                                       n * 256 * 32 * sizeof(WI))
                                 : w.k_gru_glu(n, g),
@@ -1460,7 +1473,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
 
                 // ---- skip dense (R): vector exchange ----
                 FG_STAMP(16);
-                if constexpr (LVL >= 2 && RES::ON)
+                if constexpr (LVL >= 2 && RES::ON_SKIP3)
                     fg_slice_lanes<WS, 32, 32 * FgVec<WS>::VEC, U, 256, 8>(
                         reinterpret_cast<const WS*>(res + RES::SKIP3), lds,
                         FG_OFF(skipbuf) + 512, FG_OFF(skipbuf) + 512, 256, tid,
@@ -1490,7 +1503,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 FG_STAMP(18);
                 // ---- skip GLU (R) + output layer (K): 1 exchange ----
-                if constexpr (RES::ON)
+                if constexpr (RES::ON_SKIPGLU)
                     fg_slice_lanes<WI, 32, 32 * FgVec<WI>::VEC, U, 256, 8>(
                         reinterpret_cast<const WI*>(res + RES::SKIPGLU), lds,
                         FG_OFF(f1), FG_OFF(f1), 256, tid, v);
@@ -1508,7 +1521,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 __syncthreads();
                 FG_STAMP(19);
                 fg_slice_pair<WS, 64, U>(
-                    RES::ON ? reinterpret_cast<const WS*>(res + RES::OUT)
+                    RES::ON_OUT ? reinterpret_cast<const WS*>(res + RES::OUT)
                             : w.k_out(g),
                     lds, FG_OFF(own), tid, v);
                 FG_STAMP(20);
