@@ -1247,8 +1247,8 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 // subframe] columns of W_ih, and all of the skip dense layer but
                 // the last GRU's columns. Those products are streamed UNDER the
                 // exchanges - between publishing this member's granules and
-                // polling for the others', partial sums into the reduction
-                // buffers R / R', collected behind the exchange's own barrier -
+                // polling for the others', reduced inside their waves, the
+                // rows' lead lanes storing gh / gil / skpre themselves -
                 // so that a granule round trip carries ~1 us of weight stream
                 // instead of a poll loop and the slices on the dependency chain
                 // shrink to the columns that really wait. Schedule (level 2):
@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 //   E6 output       W_hh[1] h   (for the NEXT step)
                 // (level 1: W_hh[n] h under the exchange in front of cell n)
                 constexpr int LVL = FG_UNDER(WT);
-                auto under_hh = [&](int n, auto pb) __attribute__((always_inline)) {
+                auto under_hh = [&](int n) __attribute__((always_inline)) {
                     float unused[U];
                     // (opaque thread id again: without it this slice's weight
                     // addresses are computed ahead of the exchange and the
@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                             L[u].gh[n][FgLanes<8>::row(tid)] = unused[u];
                     }
                 };
-                auto under_ih = [&](int n, auto pb) __attribute__((always_inline)) {
+                auto under_ih = [&](int n) __attribute__((always_inline)) {
                     float unused[U];
                     fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 128, 8>(
                         w.gru_ih(n) + 256 * 768 + g * 96 * FgVec<WI>::VEC, lds,
@@ -1295,14 +1295,6 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                             L[u].gil[n][FgLanes<8>::row(tid)] = unused[u];
                     }
                 };
-                // which 0: -> gh[n] (W_hh h), 1: -> gil[n] (W_ih lookback part)
-                auto collect96 = [&](int which, int n, auto pb)
-                    __attribute__((always_inline)) {
-                    // (nothing left to do: see under_hh)
-                    (void)which; (void)n; (void)pb;
-                };
-                using PB2 = std::integral_constant<int, 2>;
-                using PB3 = std::integral_constant<int, 3>;
 
                 // ---- framewise conv (R) + its GLU gate (K): 1 exchange ----
                 fg_slice_lanes<WS, 32, 256 * FgVec<WS>::VEC, U, 520, 16>(
@@ -1327,14 +1319,11 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 if constexpr (LVL >= 2) {
                     fg_exchange_sum<U, 256, 32, true>(
                         c, v, m, lds, tid, tot, ext, [&]() {
-                            under_ih(0, PB2{}); under_ih(1, PB3{}); });
-                    collect96(1, 0, PB2{});
-                    collect96(1, 1, PB3{});
+                            under_ih(0); under_ih(1); });
                 } else if constexpr (LVL == 1) {
                     fg_exchange_sum<U, 256, 32, true>(
                         c, v, m, lds, tid, tot, ext,
-                        [&]() { under_hh(0, PB2{}); });
-                    collect96(0, 0, PB2{});
+                        [&]() { under_hh(0); });
                 } else {
                     fg_exchange_sum<U, 256, 32, true>(c, v, m, lds, tid, tot, ext);
                 }
@@ -1411,14 +1400,13 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     if (LVL >= 2 && n == 0) {
                         fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext,
-                            [&]() { under_hh(2, PB2{}); });
-                        collect96(0, 2, PB2{});
+                            [&]() { under_hh(2); });
                     } else if (LVL >= 2 && n == 1) {
                         // skip dense layer (fargan.py:317-322), columns
                         // [fwconv | lookback | previous]: known since E1
                         fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext, [&]() {
-                                under_ih(2, PB2{});
+                                under_ih(2);
                                 float sb[U];
                                 fg_slice_lanes<WS, 32, 256 * FgVec<WS>::VEC, U,
                                                384, 16>(
@@ -1432,7 +1420,6 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                                         L[u].skpre[FgLanes<16>::row(tid)] = sb[u];
                                 }
                             });
-                        collect96(1, 2, PB2{});
                     } else if (LVL >= 2) {
                         // ... and columns [g0 | g1]
                         fg_exchange_sum<U, 256, 32, true>(
@@ -1454,8 +1441,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     } else if (LVL == 1 && n < 2) {
                         fg_exchange_sum<U, 256, 32, true>(
                             c, v, m, lds, tid, tot, ext,
-                            [&]() { under_hh(n + 1, PB2{}); });
-                        collect96(0, n + 1, PB2{});
+                            [&]() { under_hh(n + 1); });
                     } else {
                         fg_exchange_sum<U, 256, 32, true>(c, v, m, lds, tid, tot, ext);
                     }
@@ -1496,8 +1482,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 }
                 if constexpr (LVL >= 2) {
                     fg_exchange<U, 32, 8>(c, m, lds, FG_OFF(f1), tid,
-                                          [&]() { under_hh(0, PB2{}); });
-                    collect96(0, 0, PB2{});
+                                          [&]() { under_hh(0); });
                 } else {
                     fg_exchange<U, 32, 8>(c, m, lds, FG_OFF(f1), tid);
                 }
@@ -1527,8 +1512,7 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 FG_STAMP(20);
                 if constexpr (LVL >= 2) {
                     fg_exchange_sum<U, 64, 0, true>(c, v, v, lds, tid, tot, ext,
-                                              [&]() { under_hh(1, PB2{}); });
-                    collect96(0, 1, PB2{});
+                                              [&]() { under_hh(1); });
                 } else {
                     fg_exchange_sum<U, 64, 0, true>(c, v, v, lds, tid, tot, ext);
                 }
