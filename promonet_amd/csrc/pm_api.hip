@@ -2191,7 +2191,7 @@ static int fargan_launch(
         const int U = a.B <= resident ? 1 : a.B <= 2 * resident ? 2 : FG_UMAX;
         const int groups = (a.B + U - 1) / U;
         ca.nclusters = groups < resident ? groups : resident;
-        const dim3 grid(ca.nclusters * FG_G), block(FG_THREADS);
+        const dim3 grid(ca.nclusters * FG_G), block(FG_CT);
         // (+ the LDS-resident short slices of a one-utterance cluster)
         const size_t smem = (size_t)U * sizeof(FgLds) +
                             (U == 1 ? FgResident<WT, 1>::BYTES : 0);

@@ -546,6 +546,11 @@ __global__ __launch_bounds__(256) void pm_fargan_cond_kernel(
 // All other state (GRU states, sample history) is replicated per workgroup.
 // ===========================================================================
 #define FG_G 8
+// threads of a cluster member (the one-workgroup-per-utterance kernel keeps
+// FG_THREADS)
+#ifndef FG_CT
+#define FG_CT 768
+#endif
 
 #define FG_UMAX 4              // utterances a cluster advances in lockstep
 #ifndef FG_INFLIGHT
@@ -584,11 +589,11 @@ struct FgLds {
     float f1[FG_HOP];
     float prev[FG_PREV];
     float own[64];             // this member's slice of a row-split output
-    float part[FG_THREADS];    // reduction buffer P (and the exchanges')
-    float part2[FG_THREADS];
-    float part3[FG_THREADS];   // reduction buffer Q (see fg_slice)
-    float part4[FG_THREADS];   // reduction buffers R, R': slices run under an
-    float part5[FG_THREADS];   // exchange (see the step loop)
+    float part[FG_CT];    // reduction buffer P (and the exchanges')
+    float part2[FG_CT];
+    float part3[FG_CT];   // reduction buffer Q (see fg_slice)
+    float part4[FG_CT];   // reduction buffers R, R': slices run under an
+    float part5[FG_CT];   // exchange (see the step loop)
     float gh[3][96];           // W_hh h of the three GRU cells, computed ahead
     float gil[3][96];          // W_ih[:, 256:384] [lookback | previous subframe]
     float skpre[32];           // the skip dense layer without its last input
@@ -707,7 +712,7 @@ template <int U, int R, int E, bool PAIRED = false, class Under = FgNoOverlap>
 __device__ __forceinline__ void fg_exchange_sum(
     FgCluster& c, const float (&part)[U], const float (&extra)[U], float* lds,
     int tid, float (&total)[U], float (&ext)[U], Under under = Under()) {
-    static_assert(R + E <= FG_SLOTS && R <= FG_THREADS, "exchange geometry");
+    static_assert(R + E <= FG_SLOTS && R <= FG_CT, "exchange geometry");
     c.epoch += 1u;
     const unsigned epoch = c.epoch;
     if (PAIRED ? ((tid & 32) == 0 && (tid >> 6) < R / 32) : tid < R) {
@@ -795,7 +800,7 @@ __host__ __device__ constexpr int fg_pbuf() {
 template <int RW, int U, int PB>
 __device__ __forceinline__ void fg_slice_sum(
     const float* lds, int tid, float (&sum)[U]) {
-    constexpr int PARTS = FG_THREADS / RW;
+    constexpr int PARTS = FG_CT / RW;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         float t = 0.f;
@@ -817,7 +822,7 @@ __device__ __forceinline__ void fg_slice(
     // per-thread addresses of a slice are computed here, not earlier)
     if constexpr (U >= 2) asm volatile("" : "+v"(tid));
     constexpr int VEC = FgVec<WT>::VEC;
-    constexpr int PARTS = FG_THREADS / RW;
+    constexpr int PARTS = FG_CT / RW;
     constexpr int BLOCKS = KPAD / VEC;
     constexpr int NB = (BLOCKS + PARTS - 1) / PARTS;   // blocks per thread
     const int row = tid % RW, p = tid / RW;
@@ -895,10 +900,11 @@ __device__ __forceinline__ void fg_slice(
 // bits (each step adds the same two partial sums in either order)
 template <int LPR>
 __device__ __forceinline__ float fg_lane_sum(float v, int tid) {
-    static_assert(LPR == 8 || LPR == 16, "lanes per row");
-    // lane bits: LPR 8 -> j = bits 3-5; LPR 16 -> j = bits 2-5
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(
-        0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));        // row_ror:8
+    static_assert(LPR == 4 || LPR == 8 || LPR == 16, "lanes per row");
+    // lane bits: LPR 4 -> j = bits 4-5; 8 -> bits 3-5; 16 -> bits 2-5
+    if constexpr (LPR >= 8)
+        v += __uint_as_float(__builtin_amdgcn_update_dpp(
+            0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));    // row_ror:8
     if constexpr (LPR == 16)
         v += __uint_as_float(__builtin_amdgcn_update_dpp(
             0u, __float_as_uint(v), 0x124, 0xf, 0xf, false));    // row_ror:4
@@ -929,7 +935,7 @@ __device__ __forceinline__ void fg_slice_lanes(
     constexpr int BLOCKS = KPAD / VEC;
     constexpr int NB = (BLOCKS + LPR - 1) / LPR;
     constexpr int RPW = 64 / LPR;
-    static_assert(RW % RPW == 0 && RW * LPR <= FG_THREADS, "slice geometry");
+    static_assert(RW % RPW == 0 && RW * LPR <= FG_CT, "slice geometry");
     const int lane = tid & 63, j = lane / RPW;
     const int row = (tid >> 6) * RPW + lane % RPW;
     float acc[U];
@@ -1044,7 +1050,7 @@ template <class T, int RW, int RPAD, int KPAD>
 __device__ __forceinline__ void fg_pin(char* dst, const T* src, int tid) {
     constexpr int VEC = FgVec<T>::VEC;
     constexpr int UNITS = KPAD / VEC * RW;      // 16-byte pieces
-    for (int i = tid; i < UNITS; i += FG_THREADS) {
+    for (int i = tid; i < UNITS; i += FG_CT) {
         const int b = i / RW, r = i % RW;
         reinterpret_cast<uint4*>(dst)[i] = *reinterpret_cast<const uint4*>(
             src + ((size_t)b * RPAD + r) * VEC);
@@ -1078,12 +1084,12 @@ struct FarganClusterArgs {
 // latency of a layer (an L2-and-beyond round trip) is shared U ways. U = 1 is
 // the batch <= 32 case (one utterance per cluster, 32 clusters = 256 CUs).
 template <class WT, int U>
-__global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
+__global__ __launch_bounds__(FG_CT) void pm_fargan_cluster_kernel(
     FarganClusterArgs ca, FarganWeights<WT> w) {
     const FarganArgs& a = ca.f;
     typedef typename FgTypes<WT>::S WS;
     typedef typename FgTypes<WT>::I WI;
-    constexpr int NT = FG_THREADS;
+    constexpr int NT = FG_CT;
     constexpr int CPAD = 376;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // FgLds[U]
     FgLds* L = reinterpret_cast<FgLds*>(lds);
@@ -1260,6 +1266,8 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                 //   E6 output       W_hh[1] h   (for the NEXT step)
                 // (level 1: W_hh[n] h under the exchange in front of cell n)
                 constexpr int LVL = FG_UNDER(WT);
+                // lanes a row of the 96-row GRU slices: all FG_CT threads
+                constexpr int GLPR = FG_CT >= 768 ? 8 : 4;
                 auto under_hh = [&](int n) __attribute__((always_inline)) {
                     float unused[U];
                     // (opaque thread id again: without it this slice's weight
@@ -1274,25 +1282,25 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     // (reduced inside the wave too: the lead lane of a row
                     // writes gh[n] itself - nobody reads it before the
                     // exchange's barrier - so there is nothing to collect)
-                    fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 256, 8>(
+                    fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 256, GLPR>(
                         w.gru_hh(n) + g * 96 * FgVec<WI>::VEC, lds, hoff, hoff,
                         256, tid, unused);
-                    if (FgLanes<8>::lead(tid, 96)) {
+                    if (FgLanes<GLPR>::lead(tid, 96)) {
 #pragma unroll
                         for (int u = 0; u < U; ++u)
-                            L[u].gh[n][FgLanes<8>::row(tid)] = unused[u];
+                            L[u].gh[n][FgLanes<GLPR>::row(tid)] = unused[u];
                     }
                 };
                 auto under_ih = [&](int n) __attribute__((always_inline)) {
                     float unused[U];
-                    fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 128, 8>(
+                    fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 128, GLPR>(
                         w.gru_ih(n) + 256 * 768 + g * 96 * FgVec<WI>::VEC, lds,
                         FG_OFF(skipbuf) + 1024, FG_OFF(skipbuf) + 1024, 128, tid,
                         unused);
-                    if (FgLanes<8>::lead(tid, 96)) {
+                    if (FgLanes<GLPR>::lead(tid, 96)) {
 #pragma unroll
                         for (int u = 0; u < U; ++u)
-                            L[u].gil[n][FgLanes<8>::row(tid)] = unused[u];
+                            L[u].gil[n][FgLanes<GLPR>::row(tid)] = unused[u];
                     }
                 };
 
@@ -1343,11 +1351,11 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                     // this member's 32 units x 3 gates = packed rows g*96 ..
                     float gi[U];
                     if constexpr (LVL >= 2)
-                        fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 256, 8>(
+                        fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 256, GLPR>(
                             w.gru_ih(n) + g * 96 * FgVec<WI>::VEC, lds, xa, xa,
                             256, tid, gi);
                     else
-                        fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 384, 8>(
+                        fg_slice_lanes<WI, 96, 768 * FgVec<WI>::VEC, U, 384, GLPR>(
                             w.gru_ih(n) + g * 96 * FgVec<WI>::VEC, lds, xa,
                             FG_OFF(skipbuf) + 1024, 256, tid, gi);
                     if constexpr (LVL == 0) {
@@ -1362,8 +1370,8 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                         }
                     }
                     FG_STAMP(4 + 4 * n);
-                    if (FgLanes<8>::lead(tid, 96)) {
-                        const int row = FgLanes<8>::row(tid);
+                    if (FgLanes<GLPR>::lead(tid, 96)) {
+                        const int row = FgLanes<GLPR>::row(tid);
 #pragma unroll
                         for (int u = 0; u < U; ++u)
                             L[u].part2[row] = LVL >= 2
@@ -1526,8 +1534,8 @@ __global__ __launch_bounds__(FG_THREADS) void pm_fargan_cluster_kernel(
                             a.out[((size_t)ut[u] * T + t) * FG_HOP + s * FG_SUB +
                                   tid] = sample;
                         S.prev[(base + tid) & (FG_PREV - 1)] = sample;
-                    } else if (tid >= 256 && tid < 256 + FG_SUBIN) {
-                        S.subin[FG_SUBIN + tid - 256] = S.subin[tid - 256];
+                    } else if (tid < FG_SUB + FG_SUBIN) {
+                        S.subin[FG_SUBIN + tid - FG_SUB] = S.subin[tid - FG_SUB];
                     }
                 }
                 base = (base + FG_SUB) & (FG_PREV - 1);
