@@ -38,6 +38,14 @@
 // 10 log10(x) = (10 / log2(10)) log2(x): one v_log_f32 (1 ulp) instead of the
 // ~25-instruction log10f, 8 times per lane and frame
 #define PM_DB_PER_LOG2 3.01029995663981195f
+// sqrt(|X|^2 + 1e-6): the argument is >= 1e-6, never subnormal, so the bare
+// v_sqrt_f32 (1 ulp) is enough; sqrtf() wraps it in a subnormal-scaling
+// sequence (7 more instructions, 8 times per lane and frame)
+#ifdef PM_FFT_LIBM_SQRT
+#define PM_FFT_SQRT(x) sqrtf(x)
+#else
+#define PM_FFT_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#endif
 
 struct FftArgs {
     const float* audio;      // (B, N)
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
             const float re = ex + wx.x, im = ey + wx.y;
             const float pw = re * re + im * im;
             if constexpr (EPI == 1 || EPI == 4) {
-                ost[k * OS + fl] = sqrtf(pw + 1e-6f);
+                ost[k * OS + fl] = PM_FFT_SQRT(pw + 1e-6f);
             } else {
                 const float v = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, pw));
                 if constexpr (EPI == 2) {
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
             const float re = z0.x - z0.y;
             const float pw = re * re;
             if constexpr (EPI == 1 || EPI == 4) {
-                ost[512 * OS + fl] = sqrtf(pw + 1e-6f);
+                ost[512 * OS + fl] = PM_FFT_SQRT(pw + 1e-6f);
             } else {
                 const float v = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, pw));
                 if constexpr (EPI == 2) {
