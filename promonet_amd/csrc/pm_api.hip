@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -1610,6 +1611,34 @@ extern "C" int pm_stft_set_frames_per_group(int frames) {
     return PM_OK;
 }
 
+// One geometry of the FFT kernel as PERSISTENT workgroups: the grid is what
+// the device holds at once (occupancy x CUs, asked once per geometry) and a
+// workgroup walks the (utterance, group of NW x FPW frames) pairs with that
+// stride.
+template <int EPI, int NW, int FPW>
+static int fft_launch_shape(FftArgs& a, hipStream_t s) {
+    auto kern = pm_stft_fft_kernel<EPI, NW, FPW>;
+    constexpr int smem = pm_fft_smem_bytes<EPI, NW, FPW>();
+    HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
+    static std::atomic<int> per_cu{0};
+    int resident = per_cu.load(std::memory_order_relaxed);
+    if (resident == 0) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &resident, kern, NW * 64, smem));
+        if (resident < 1) resident = 1;
+        per_cu.store(resident, std::memory_order_relaxed);
+    }
+    a.groups = (a.T + NW * FPW - 1) / (NW * FPW);
+    const long long total = (long long)a.groups * a.B;
+    if (total > 0x7fffffffLL) return fail(PM_EINVAL, "batch too large");
+    a.total = (int)total;
+    const int cus = pm_device_cus() > 0 ? pm_device_cus() : 256;
+    const int grid = (int)std::min<long long>(total, (long long)resident * cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, s, a);
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
 // `frames_per_group`: read ONCE per API call by the caller (pm_loudness runs
 // two passes whose per-group maxima must be indexed the same way)
 template <int EPI>
@@ -1624,32 +1653,21 @@ static int fft_launch(FftArgs& a, hipStream_t s,
     if (a.B > 65535) return fail(PM_EINVAL, "batch too large (max 65535)");
     int rc = get_fft_tables(&a.tables, s);
     if (rc) return rc;
-    if (frames_per_group == 32) {
-        auto kern = pm_stft_fft_kernel<EPI, 8, 4>;
-        constexpr int smem = pm_fft_smem_bytes<EPI, 8, 4>();
-        HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
-        hipLaunchKernelGGL(kern, dim3((a.T + 31) / 32, a.B), dim3(512), smem,
-                           s, a);
-    } else if constexpr (EPI == 1 || EPI == 4) {
-        // 16 frames by EIGHT waves of two frames: two 512-thread workgroups
-        // per CU at 128 registers = four waves per SIMD to cover the eight
-        // wave-private LDS hand-overs of a frame (profiles/r04/stft_pmc.txt:
-        // magnitude 53.6 -> 50.4 us, log-mel 62.7 -> 50.6 us; the dB epilogues
-        // of the loudness passes want 166 registers and lose 50 % this way)
-        auto kern = pm_stft_fft_kernel<EPI, 8, 2>;
-        constexpr int smem = pm_fft_smem_bytes<EPI, 8, 2>();
-        HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
-        hipLaunchKernelGGL(kern, dim3((a.T + 15) / 16, a.B), dim3(512), smem,
-                           s, a);
-    } else {
-        auto kern = pm_stft_fft_kernel<EPI, 4, 4>;
-        constexpr int smem = pm_fft_smem_bytes<EPI, 4, 4>();
-        HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
-        hipLaunchKernelGGL(kern, dim3((a.T + 15) / 16, a.B), dim3(256), smem,
-                           s, a);
-    }
-    HIP_TRY(hipGetLastError());
-    return PM_OK;
+    // 16 frames by EIGHT waves of two frames for the magnitude / log-mel
+    // launches: two 512-thread workgroups per CU at 128 registers = four
+    // waves per SIMD to cover the eight wave-private LDS hand-overs of a frame
+    // (profiles/r04/stft_pmc.txt: magnitude 53.6 -> 50.4 us, log-mel 62.7 ->
+    // 50.6 us; the dB epilogues of the loudness passes want 166 registers and
+    // lose 50 % this way: they stay on four waves of four frames)
+    if (frames_per_group == 32)
+        return fft_launch_shape<EPI, 8, 4>(a, s);
+#ifndef PM_FFT_LOUD_8X2
+#define PM_FFT_LOUD_8X2 0
+#endif
+    if constexpr (EPI == 1 || EPI == 4 || PM_FFT_LOUD_8X2)
+        return fft_launch_shape<EPI, 8, 2>(a, s);
+    else
+        return fft_launch_shape<EPI, 4, 4>(a, s);
 }
 
 extern "C" int pm_stft_magnitude(

@@ -51,13 +51,16 @@ struct FftArgs {
     const float* audio;      // (B, N)
     float* out;
     const float* tables;     // PM_FFT_TAB_FLOATS
-    float* group_max;        // (B, gridDim.x): every workgroup's maximum dB (EPI
-                             // 2 writes it, EPI 3 folds the utterance's row)
+    float* group_max;        // (B, groups): every group's maximum dB (EPI 2
+                             // writes it, EPI 3 folds the utterance's row)
     const float* weights;    // EPI 3: (513) A-weights; EPI 4: mel basis (M, 513)
     const int* mel_span;     // EPI 4: pm_mel_csr_kernel's table (lo, hi, offset
                              // per filter, then the non-zero count)
     const float* mel_vals;   // EPI 4: the filters' non-zero spans, compacted
     int B, N, T;
+    int groups;              // FR-frame groups per utterance
+    int total;               // groups x B: a workgroup takes blockIdx.x,
+                             // blockIdx.x + gridDim.x, ... (fft_launch)
     int rows;                // EPI 3: bands; EPI 4: mels
     int band_start[17];
     float min_db, top_db;    // EPI 3
@@ -152,8 +155,13 @@ __device__ __forceinline__ void pm_fft_load_frame(
     }
 }
 
+// (second launch bound = waves per SIMD the register allocation must leave
+// room for: four for the magnitude / log-mel shapes - two 8-wave workgroups a
+// CU - three for the loudness passes' dB epilogues, two for the 32-frame
+// groups whose staging tile leaves room for one workgroup a CU)
 template <int EPI, int NW, int FPW>
-__global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
+__global__ __launch_bounds__(NW * 64, NW * FPW == 32 ? 2 : (EPI == 1 || EPI == 4) ? 4 : 3)
+void pm_stft_fft_kernel(FftArgs a) {
     constexpr int FR = NW * FPW;
     constexpr int NT = NW * 64;
     constexpr int WS = 576;          // complex slots per wave (8 x 72)
@@ -166,10 +174,29 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * FR;
+    // Persistent workgroups: the grid is what the chip holds at once and a
+    // workgroup walks groups g = blockIdx.x, + gridDim.x, ... - the per-lane
+    // tables below (32 twiddle / window pairs and their addresses, a quarter
+    // of a two-frame wave's instructions) are set up once, not per group
+    // XCD-aware walk: workgroup w runs on XCD w % 8, so each XCD takes one
+    // contiguous eighth of the groups and its workgroups walk that eighth -
+    // neighbouring groups of an utterance share every 128-byte line of the
+    // (.., T) output rows (a group owns 64 bytes of each) and 3/4 of their
+    // first frame's samples, and now meet in ONE L2 instead of two
+    int g = blockIdx.x, stride = gridDim.x, end = a.total;
+#ifndef PM_FFT_NO_XCD
+    if ((gridDim.x & 7u) == 0u) {
+        const long long x = blockIdx.x & 7u;
+        stride = (int)(gridDim.x >> 3);
+        g = (int)(x * a.total / 8) + (int)(blockIdx.x >> 3);
+        end = (int)((x + 1) * a.total / 8);
+        if (g >= end) return;               // (workgroup-uniform)
+    }
+#endif
+    int b = g / a.groups;
+    int t0 = (g - b * a.groups) * FR;
     const int T = a.T, N = a.N;
-    const float* __restrict__ ab = a.audio + (size_t)b * N;
+    const float* ab = a.audio + (size_t)b * N;
 
     // the first frame's samples are requested before anything else
     float2 raw[8];
@@ -190,25 +217,33 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
     const float2* __restrict__ w1024 =
         reinterpret_cast<const float2*>(tab + PM_FFT_TAB_W1024);
     const int k0p = lane >> 3, m0p = lane & 7;
-    float2 win[8], twa[8], twb[8], twp[8];
+    // (the unpacking twiddles W1024^k, k = lane + 64 j, are read where they
+    // are used - 4 KB that stay in L1, coalesced - instead of holding 16 more
+    // registers across the frame loop)
+    float2 win[8], twa[8], twb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         win[i] = *reinterpret_cast<const float2*>(tab + 2 * (64 * i + lane));
         twa[i] = w512[lane * i];            // W512^(m k0), m = lane
         twb[i] = w512[8 * m0p * i];         // W64^(m0 q0)
-        twp[i] = w1024[lane + 64 * i];      // W1024^k, k = lane + 64 j
     }
-    float local_max = -INFINITY;
     [[maybe_unused]] float floor_db = 0.f;
+    [[maybe_unused]] int floor_of = -1;    // utterance floor_db belongs to
+    [[maybe_unused]] int parity = 0;       // EPI 2: reduction slots alternate
+    float2* wk = work + wave * WS;
+#pragma unroll 1
+    for (;;) {
+    float local_max = -INFINITY;
     if constexpr (EPI == 3) {
+        if (floor_of != b) {               // (workgroup-uniform)
         // the utterance maximum of pass 1 (librosa.amplitude_to_db's top_db
-        // reference): fold this utterance's per-workgroup maxima
+        // reference): fold this utterance's per-group maxima
         float m = -INFINITY;
-        const float* gm = a.group_max + (size_t)b * gridDim.x;
-        for (int i = tid; i < (int)gridDim.x; i += NT) m = fmaxf(m, gm[i]);
+        const float* gm = a.group_max + (size_t)b * a.groups;
+        for (int i = tid; i < a.groups; i += NT) m = fmaxf(m, gm[i]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float* red = reinterpret_cast<float*>(work);   // (free until the first frame)
+        float* red = reinterpret_cast<float*>(work);   // (free between groups)
         if (lane == 0) red[wave] = m;
         __syncthreads();
         m = red[0];
@@ -216,9 +251,10 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
         for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
         __syncthreads();
         floor_db = m - a.top_db;
+        floor_of = b;
+        }
     }
 
-    float2* wk = work + wave * WS;
 #pragma unroll 1
     for (int i = 0; i < FPW; ++i) {
         const int fl = wave + NW * i;       // frame of this workgroup
@@ -229,8 +265,11 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
         for (int n2 = 0; n2 < 8; ++n2)
             z[n2] = make_float2(raw[n2].x * win[n2].x, raw[n2].y * win[n2].y);
         // (the next frame's samples fly under this frame's transform)
-        if (i + 1 < FPW && t0 + fl + NW < T)
-            pm_fft_load_frame(raw, ab, t0 + fl + NW, N, lane);
+        if (i + 1 < FPW && t0 + fl + NW < T) {
+            int glane = lane;              // (opaque per frame, see `wlane`)
+            asm volatile("" : "+v"(glane));
+            pm_fft_load_frame(raw, ab, t0 + fl + NW, N, glane);
+        }
         pm_radix8(z);
 #pragma unroll
         for (int k0 = 1; k0 < 8; ++k0) z[k0] = pm_cmul(z[k0], twa[k0]);
@@ -259,6 +298,8 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
         pm_wave_lds_sync();
         // unpack: X[k] = (Z[k] + conj Z[512 - k]) / 2
         //                + W1024^k (Z[k] - conj Z[512 - k]) / (2 i)
+        int ul = lane;          // (opaque: the twiddle loads stay in the loop)
+        asm volatile("" : "+v"(ul));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = lane + 64 * j;
@@ -267,7 +308,7 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
             const float ex = 0.5f * (zk.x + zm.x), ey = 0.5f * (zk.y - zm.y);
             const float dx = 0.5f * (zk.x - zm.x), dy = 0.5f * (zk.y + zm.y);
             const float2 xo = make_float2(dy, -dx);
-            const float2 wx = pm_cmul(xo, twp[j]);
+            const float2 wx = pm_cmul(xo, w1024[ul + 64 * j]);
             const float re = ex + wx.x, im = ey + wx.y;
             const float pw = re * re + im * im;
             if constexpr (EPI == 1 || EPI == 4) {
@@ -302,34 +343,52 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
         }
     }
 
+    // the next group of this workgroup; its first frame's samples fly under
+    // the write-out of this one
+    const int gn = g + stride;
+    const bool more = gn < end;             // (workgroup-uniform)
+    const int bn = more ? gn / a.groups : b;
+    const int t0n = more ? (gn - bn * a.groups) * FR : t0;
+    const float* __restrict__ abn = a.audio + (size_t)bn * N;
+    // (opaque copies of the thread / lane index: the write-out's and this
+    // load's per-lane addresses are recomputed per group instead of being kept
+    // in registers across the frame loop, which sits at the 128-register bound
+    // of four waves per SIMD)
+    int wtid = tid, wlane = lane;
+    asm volatile("" : "+v"(wtid), "+v"(wlane));
+    if (more && t0n + wave < T) pm_fft_load_frame(raw, abn, t0n + wave, N, wlane);
+
     if constexpr (EPI == 2) {
-        // one plain store per workgroup (atomics on 32 addresses serialise)
+        // one plain store per group (atomics on 32 addresses serialise); the
+        // two sets of reduction slots alternate, so the next group's partial
+        // maxima never land on ones thread 0 has yet to read
+        static_assert(NW <= 8, "two sets of NW slots in the 64 bytes behind the work area");
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
             local_max = fmaxf(local_max, __shfl_xor(local_max, o, 64));
-        float* red = reinterpret_cast<float*>(work + NW * WS);   // (64 B behind)
+        float* red = reinterpret_cast<float*>(work + NW * WS) + 8 * parity;
+        parity ^= 1;
         if (lane == 0) red[wave] = local_max;
         __syncthreads();
         if (tid == 0) {
             float m = red[0];
 #pragma unroll
             for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
-            a.group_max[(size_t)b * gridDim.x + blockIdx.x] = m;
+            a.group_max[(size_t)b * a.groups + t0 / FR] = m;
         }
-        return;
-    }
+    } else {
     __syncthreads();
-    const int nf = min(FR, T - t0);         // frames this workgroup owns
+    const int nf = min(FR, T - t0);         // frames this group owns
     if (EPI == 1 || (EPI == 3 && a.rows == PM_FFT_BINS)) {
         float* ob = a.out + (size_t)b * PM_FFT_BINS * T + t0;
-        for (int idx = tid; idx < PM_FFT_BINS * FR; idx += NT) {
+        for (int idx = wtid; idx < PM_FFT_BINS * FR; idx += NT) {
             const int bin = idx / FR, c = idx % FR;
             if (c < nf) ob[(size_t)bin * T + c] = ost[bin * OS + c];
         }
     } else if constexpr (EPI == 3) {
         // band means, rows summed in ascending order (loudness.py:96-111)
         float* ob = a.out + (size_t)b * a.rows * T + t0;
-        for (int idx = tid; idx < a.rows * FR; idx += NT) {
+        for (int idx = wtid; idx < a.rows * FR; idx += NT) {
             const int band = idx / FR, c = idx % FR;
             if (c >= nf) continue;
             const int r0 = a.band_start[band], r1 = a.band_start[band + 1];
@@ -342,7 +401,7 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
         // (two loops, not one pointer select: a pointer that may be LDS or
         // global is a FLAT pointer, and flat loads cost this epilogue 60 us)
         float* ob = a.out + (size_t)b * a.rows * T + t0;
-        for (int idx = tid; idx < a.rows * FR; idx += NT) {
+        for (int idx = wtid; idx < a.rows * FR; idx += NT) {
             const int m = idx / FR, c = idx % FR;
             if (c >= nf) continue;
             const int lo = a.mel_span[3 * m], n = a.mel_span[3 * m + 1] - lo;
@@ -363,6 +422,11 @@ __global__ __launch_bounds__(NW * 64) void pm_stft_fft_kernel(FftArgs a) {
             ob[(size_t)m * T + c] = v;
         }
     }
+    }   // (EPI != 2)
+    if (!more) break;
+    if constexpr (EPI != 2) __syncthreads();   // staging tile read out
+    g = gn; b = bn; t0 = t0n; ab = abn;
+    }   // groups of this workgroup
 }
 
 // Compact form of a (M, F) filterbank: per row the first / one-past-last
