@@ -893,7 +893,7 @@ static int forward_impl(
              (double)B * L * (h->c_last + 1) * 4, {
             if (C == 32 && h->c_last == 32) {
                 constexpr int T32 = 128;   // 38 KB of LDS: four per CU
-                const size_t smem = (size_t)32 * (PM_OUT32_RL(T32) + 8) * sizeof(float);
+                const size_t smem = (size_t)32 * PM_OUT32_RL(T32) * sizeof(float);
                 hipLaunchKernelGGL(pm_out_conv32_kernel<T32>,
                                    dim3((L + T32 * 2 - 1) / (T32 * 2), B),
                                    dim3(T32), smem, s, buf[xi], h->out_w, out,

@@ -456,9 +456,8 @@ __global__ __launch_bounds__(THREADS) void pm_out_conv_kernel(
 // bounds it: the generic kernel reads LDS twice per FMA (activation + weight).
 // Here the tile sits channel-major in LDS and every thread produces two
 // consecutive samples from an 8-sample register window per channel: four
-// conflict-free ds_read_b64 of activations and two broadcast ds_read_b128 of
-// weights feed 14 FMAs. (Weights as scalar loads: the compiler hoists all 224
-// and spills SGPRs through v_readlane - 2x slower.)
+// conflict-free ds_read_b64 of activations and the channel's 7 taps from the
+// scalar cache feed 14 FMAs.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void pm_out_conv32_kernel(
     const float* __restrict__ x, const float* __restrict__ w,
@@ -469,7 +468,6 @@ __global__ __launch_bounds__(THREADS) void pm_out_conv32_kernel(
     constexpr int ROWS = TILE + 2 * HALO;
     constexpr int RL = PM_OUT32_RL(THREADS);  // floats per channel row
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [C][RL]
-    float* wsm = sm + C * RL;                 // [C][8]: 7 taps + pad
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * TILE;
     const int L = lengths ? min(lengths[b] * len_scale, Lmax) : Lmax;
@@ -479,8 +477,6 @@ __global__ __launch_bounds__(THREADS) void pm_out_conv32_kernel(
             if (t0 + i < Lmax) yb[t0 + i] = 0.f;
         return;
     }
-    for (int i = threadIdx.x; i < C * 8; i += THREADS)
-        wsm[i] = (i & 7) < KW ? w[(i >> 3) * KW + (i & 7)] : 0.f;
     const float* xb = x + (size_t)b * Lmax * C;
     constexpr int Q = C / 4;
     // every load of the tile is in flight before the first LDS write (a
@@ -522,9 +518,17 @@ __global__ __launch_bounds__(THREADS) void pm_out_conv32_kernel(
                 *reinterpret_cast<const float2*>(sm + c * RL + first + r);
             win[r] = v.x; win[r + 1] = v.y;
         }
-        const float4 wa = *reinterpret_cast<const float4*>(wsm + c * 8);
-        const float4 wb = *reinterpret_cast<const float4*>(wsm + c * 8 + 4);
-        const float wj[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        // the channel's 7 taps as scalar loads (uniform address, scalar
+        // cache): no LDS bandwidth for weights. The opaque channel index keeps
+        // the loads in the loop - hoisted, the 224 of them spill the SGPR file
+        // through v_readlane (2x slower); two broadcast ds_read_b128 of an
+        // LDS copy instead: 0.222 against 0.212 ms (profiles/r04/ab_tail_kernels.txt)
+        int cc = c;
+        asm volatile("" : "+s"(cc));
+        const float* __restrict__ wc = w + cc * KW;
+        float wj[KW];
+#pragma unroll
+        for (int j = 0; j < KW; ++j) wj[j] = wc[j];
 #pragma unroll
         for (int j = 0; j < KW; ++j)
 #pragma unroll
