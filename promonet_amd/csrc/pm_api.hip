@@ -1839,6 +1839,15 @@ extern "C" int pm_loudness(
         a.band_start[b] = (int)(b * step);
     if (bands == 1) { a.band_start[0] = 0; a.band_start[1] = BINS; }
     a.min_db = min_db; a.top_db = 80.f;
+    // the default 8 bands: band j = bins 64 j .. 64 j + 63 (+ bin 512 in the
+    // last), reduced across the wave out of the registers (EPI 5)
+    bool aligned8 = bands == 8;
+    for (int b = 0; aligned8 && b < 8; ++b) aligned8 = a.band_start[b] == 64 * b;
+#ifdef PM_LOUD_NO_EPI5
+    aligned8 = false;
+#endif
+    if (aligned8 && a.band_start[8] == BINS)
+        return fft_launch<5>(a, s, frames_per_group);
     return fft_launch<3>(a, s, frames_per_group);
 }
 

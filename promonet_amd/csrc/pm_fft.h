@@ -24,6 +24,10 @@
 // EPI 2: utterance maximum of 10 log10(max(1e-10, |X|^2)) only (no output)
 // EPI 3: A-weighted, floored dB, band means (B, bands, T)   loudness.py:46-55,84-111
 // EPI 4: log-mel (B, mels, T)                           spectrogram.py:111-133
+// EPI 5: EPI 3 for the default 8 bands: bin lane + 64 j of a frame lies in band
+//        j (band_average's edges int(b 513 / 8) are 0, 64, ... 448, 513), so
+//        the band sums are reduced across the wave out of the registers - no
+//        513-row staging tile, 8 x FR floats of LDS instead
 #pragma once
 #include "pm_common.h"
 
@@ -118,7 +122,8 @@ __device__ __forceinline__ void pm_wave_lds_sync() {
 template <int EPI, int NW, int FPW>
 __host__ __device__ constexpr int pm_fft_smem_bytes() {
     constexpr int FR = NW * FPW;
-    return NW * 576 * 8 + (EPI == 2 ? 64 : PM_FFT_BINS * (FR + 1) * 4) +
+    return NW * 576 * 8 +
+           (EPI == 2 ? 64 : EPI == 5 ? 8 * (FR + 1) * 4 : PM_FFT_BINS * (FR + 1) * 4) +
            (EPI == 4 ? PM_FFT_MEL_CAP * 4 : 0);
 }
 
@@ -234,7 +239,7 @@ void pm_stft_fft_kernel(FftArgs a) {
 #pragma unroll 1
     for (;;) {
     float local_max = -INFINITY;
-    if constexpr (EPI == 3) {
+    if constexpr (EPI == 3 || EPI == 5) {
         if (floor_of != b) {               // (workgroup-uniform)
         // the utterance maximum of pass 1 (librosa.amplitude_to_db's top_db
         // reference): fold this utterance's per-group maxima
@@ -300,6 +305,7 @@ void pm_stft_fft_kernel(FftArgs a) {
         //                + W1024^k (Z[k] - conj Z[512 - k]) / (2 i)
         int ul = lane;          // (opaque: the twiddle loads stay in the loop)
         asm volatile("" : "+v"(ul));
+        [[maybe_unused]] float bs[8];       // EPI 5: this lane's bin of band j
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = lane + 64 * j;
@@ -320,10 +326,56 @@ void pm_stft_fft_kernel(FftArgs a) {
                 } else {
                     float u = fmaxf(v, floor_db) + a.weights[k];
                     u = u < a.min_db ? a.min_db : u;
-                    ost[k * OS + fl] = u;
+                    if constexpr (EPI == 5) bs[j] = u;
+                    else ost[k * OS + fl] = u;
                 }
             }
         }
+        if constexpr (EPI == 5) {
+            // bin 512 (Re Z[0] - Im Z[0]) closes band 7: lane 0 adds it
+            const float2 z0 = wk[0];
+            const float re0 = z0.x - z0.y;
+            const float v0 = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, re0 * re0));
+            float u0 = fmaxf(v0, floor_db) + a.weights[512];
+            u0 = u0 < a.min_db ? a.min_db : u0;
+            if (lane == 0) bs[7] += u0;
+            // 8 sums over 64 lanes in 10 exchanges: three halving steps (a
+            // lane keeps the bands of its own half and adds the partner's
+            // values for them), then three plain ones; lane 8 band ends up
+            // with the sum of band `band`
+            float v4[4], v2[2], v1;
+            {
+                const bool hi = lane & 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float mine = hi ? bs[q + 4] : bs[q];
+                    const float send = hi ? bs[q] : bs[q + 4];
+                    v4[q] = mine + __shfl_xor(send, 32, 64);
+                }
+            }
+            {
+                const bool hi = lane & 16;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float mine = hi ? v4[q + 2] : v4[q];
+                    const float send = hi ? v4[q] : v4[q + 2];
+                    v2[q] = mine + __shfl_xor(send, 16, 64);
+                }
+            }
+            {
+                const bool hi = lane & 8;
+                const float mine = hi ? v2[1] : v2[0];
+                const float send = hi ? v2[0] : v2[1];
+                v1 = mine + __shfl_xor(send, 8, 64);
+            }
+            v1 += __shfl_xor(v1, 4, 64);
+            v1 += __shfl_xor(v1, 2, 64);
+            v1 += __shfl_xor(v1, 1, 64);
+            if ((lane & 7) == 0) {
+                const int band = lane >> 3;
+                ost[band * OS + fl] = v1 / (band == 7 ? 65.f : 64.f);
+            }
+        } else
         if (lane == 0) {                    // bin 512: Re Z[0] - Im Z[0]
             const float2 z0 = wk[0];
             const float re = z0.x - z0.y;
@@ -384,6 +436,12 @@ void pm_stft_fft_kernel(FftArgs a) {
         for (int idx = wtid; idx < PM_FFT_BINS * FR; idx += NT) {
             const int bin = idx / FR, c = idx % FR;
             if (c < nf) ob[(size_t)bin * T + c] = ost[bin * OS + c];
+        }
+    } else if constexpr (EPI == 5) {
+        float* ob = a.out + (size_t)b * 8 * T + t0;
+        for (int idx = wtid; idx < 8 * FR; idx += NT) {
+            const int band = idx / FR, c = idx % FR;
+            if (c < nf) ob[(size_t)band * T + c] = ost[band * OS + c];
         }
     } else if constexpr (EPI == 3) {
         // band means, rows summed in ascending order (loudness.py:96-111)
