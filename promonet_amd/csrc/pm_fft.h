@@ -238,7 +238,7 @@ void pm_stft_fft_kernel(FftArgs a) {
     float2* wk = work + wave * WS;
 #pragma unroll 1
     for (;;) {
-    float local_max = -INFINITY;
+    float local_max = EPI == 2 ? 0.f : -INFINITY;   // (EPI 2: of |X|^2 >= 0)
     if constexpr (EPI == 3 || EPI == 5) {
         if (floor_of != b) {               // (workgroup-uniform)
         // the utterance maximum of pass 1 (librosa.amplitude_to_db's top_db
@@ -319,11 +319,13 @@ void pm_stft_fft_kernel(FftArgs a) {
             const float pw = re * re + im * im;
             if constexpr (EPI == 1 || EPI == 4) {
                 ost[k * OS + fl] = PM_FFT_SQRT(pw + 1e-6f);
+            } else if constexpr (EPI == 2) {
+                // (the dB map is monotonic: the maximum is taken over |X|^2
+                // and mapped once per group)
+                local_max = fmaxf(local_max, pw);
             } else {
                 const float v = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, pw));
-                if constexpr (EPI == 2) {
-                    local_max = fmaxf(local_max, v);
-                } else {
+                {
                     float u = fmaxf(v, floor_db) + a.weights[k];
                     u = u < a.min_db ? a.min_db : u;
                     if constexpr (EPI == 5) bs[j] = u;
@@ -382,11 +384,11 @@ void pm_stft_fft_kernel(FftArgs a) {
             const float pw = re * re;
             if constexpr (EPI == 1 || EPI == 4) {
                 ost[512 * OS + fl] = PM_FFT_SQRT(pw + 1e-6f);
+            } else if constexpr (EPI == 2) {
+                local_max = fmaxf(local_max, pw);
             } else {
                 const float v = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, pw));
-                if constexpr (EPI == 2) {
-                    local_max = fmaxf(local_max, v);
-                } else {
+                {
                     float u = fmaxf(v, floor_db) + a.weights[512];
                     u = u < a.min_db ? a.min_db : u;
                     ost[512 * OS + fl] = u;
@@ -426,7 +428,8 @@ void pm_stft_fft_kernel(FftArgs a) {
             float m = red[0];
 #pragma unroll
             for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
-            a.group_max[(size_t)b * a.groups + t0 / FR] = m;
+            a.group_max[(size_t)b * a.groups + t0 / FR] =
+                PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, m));
         }
     } else {
     __syncthreads();
