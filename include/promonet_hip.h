@@ -401,6 +401,13 @@ int pm_stft_mel(const float* audio, const void* prepared, float* out,
  * or 32 (one 8-wave workgroup, 128-byte output rows). Per host thread; an API
  * call reads it once (both passes of pm_loudness use the same value).      */
 int pm_stft_set_frames_per_group(int frames);
+/* The launch geometry one FFT transform would take for (batch, samples) on the
+ * current device and host thread: `total_groups` (utterance, frame-group)
+ * pairs walked by `workgroups` persistent workgroups (= min(total, occupancy x
+ * CUs)); transform 1 = magnitude, 4 = log-mel, 2 / 3 / 5 = the loudness passes
+ * (maximum, generic bands, the default 8 bands). Launches nothing.           */
+int pm_stft_launch_info(int transform, int batch, int samples,
+                        int* total_groups, int* workgroups);
 /* spectrogram.linear_to_mel (spectrogram.py:111-133): log(basis @ spec),
  * optional clamp: spec (B, F, T), basis (Mel, F) -> (B, Mel, T)           */
 int pm_linear_to_mel(const float* spec, const float* basis, float* out,

@@ -131,14 +131,20 @@ def derived():
 derived()
 
 
+# every override applied so far (a `spawn`ed worker process imports the package
+# with the defaults above: synthesize.core re-applies these in its workers)
+OVERRIDES = {}
+
+
 def configure(**overrides):
     """Override constants BEFORE constructing models (the reference does this
     once, at import, from `--config` files: promonet/__init__.py:7-15)."""
     import promonet_amd
     for key, value in overrides.items():
-        if key not in globals():
+        if key not in globals() or key == 'OVERRIDES':
             raise ValueError(f'Unknown configuration parameter {key}')
         globals()[key] = value
+        OVERRIDES[key] = value
     derived()
     for key, value in globals().items():
         if key.isupper():

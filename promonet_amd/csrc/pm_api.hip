@@ -775,7 +775,7 @@ static int forward_impl(
         // (split-f16 operands on a batch long enough for the skewed walk: Block
         // by Block - three launches that recompute nothing beat the fused
         // whole-MRF launch and its 23 % halo there, pm_launch.h)
-        const bool x3_skew = esz(st.dtype) == 4 && st.cout_pad == 32 &&
+        const bool x3_skew = pm_x3skew_id(st.dtype) && st.cout_pad == 32 &&
             p.scratch && pm_device_cus() > 0 &&
             (L / 512) / std::max(1, pm_device_cus() / B) >= 4;
         if (fusion_level() >= 2 && !x3_skew && h->cfg.num_resblocks == 3 &&
@@ -1615,8 +1615,9 @@ extern "C" int pm_stft_set_frames_per_group(int frames) {
 // the device holds at once (occupancy x CUs, asked once per geometry) and a
 // workgroup walks the (utterance, group of NW x FPW frames) pairs with that
 // stride.
+// `dry` (pm_stft_launch_info): fill a.groups / a.total / a.grid, launch nothing
 template <int EPI, int NW, int FPW>
-static int fft_launch_shape(FftArgs& a, hipStream_t s) {
+static int fft_launch_shape(FftArgs& a, hipStream_t s, int* dry_grid = nullptr) {
     auto kern = pm_stft_fft_kernel<EPI, NW, FPW>;
     constexpr int smem = pm_fft_smem_bytes<EPI, NW, FPW>();
     HIP_TRY(pm_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem));
@@ -1634,6 +1635,7 @@ static int fft_launch_shape(FftArgs& a, hipStream_t s) {
     a.total = (int)total;
     const int cus = pm_device_cus() > 0 ? pm_device_cus() : 256;
     const int grid = (int)std::min<long long>(total, (long long)resident * cus);
+    if (dry_grid) { *dry_grid = grid; return PM_OK; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, s, a);
     HIP_TRY(hipGetLastError());
     return PM_OK;
@@ -1643,16 +1645,19 @@ static int fft_launch_shape(FftArgs& a, hipStream_t s) {
 // two passes whose per-group maxima must be indexed the same way)
 template <int EPI>
 static int fft_launch(FftArgs& a, hipStream_t s,
-                      int frames_per_group = g_fft_frames_per_group) {
+                      int frames_per_group = g_fft_frames_per_group,
+                      int* dry_grid = nullptr) {
     const int pad = (NFFT - HOP) / 2;
-    if (!a.audio) return fail(PM_EINVAL, "null argument");
+    if (!a.audio && !dry_grid) return fail(PM_EINVAL, "null argument");
     if (a.B < 1 || a.N <= pad)
         return fail(PM_EINVAL, "need more than %d samples (reflect pad)", pad);
     a.T = a.N / HOP;
     if (a.T < 1) return fail(PM_EINVAL, "fewer samples than one hop");
     if (a.B > 65535) return fail(PM_EINVAL, "batch too large (max 65535)");
-    int rc = get_fft_tables(&a.tables, s);
-    if (rc) return rc;
+    if (!dry_grid) {
+        int rc = get_fft_tables(&a.tables, s);
+        if (rc) return rc;
+    }
     // 16 frames by EIGHT waves of two frames for the magnitude / log-mel
     // launches: two 512-thread workgroups per CU at 128 registers = four
     // waves per SIMD to cover the eight wave-private LDS hand-overs of a frame
@@ -1660,14 +1665,39 @@ static int fft_launch(FftArgs& a, hipStream_t s,
     // 50.6 us; the dB epilogues of the loudness passes want 166 registers and
     // lose 50 % this way: they stay on four waves of four frames)
     if (frames_per_group == 32)
-        return fft_launch_shape<EPI, 8, 4>(a, s);
+        return fft_launch_shape<EPI, 8, 4>(a, s, dry_grid);
 #ifndef PM_FFT_LOUD_8X2
 #define PM_FFT_LOUD_8X2 0
 #endif
     if constexpr (EPI == 1 || EPI == 4 || PM_FFT_LOUD_8X2)
-        return fft_launch_shape<EPI, 8, 2>(a, s);
+        return fft_launch_shape<EPI, 8, 2>(a, s, dry_grid);
     else
-        return fft_launch_shape<EPI, 4, 4>(a, s);
+        return fft_launch_shape<EPI, 4, 4>(a, s, dry_grid);
+}
+
+// The geometry the next launch of one FFT transform would take on this device
+// and host thread (tests assert that the persistent multi-group walk - more
+// groups than resident workgroups - is what they exercise). transform: 1
+// magnitude, 4 log-mel, 2 / 3 / 5 the loudness passes (maximum, generic bands,
+// the 8 default bands).
+extern "C" int pm_stft_launch_info(
+    int transform, int B, int N, int* total_groups, int* workgroups) {
+    if (!total_groups || !workgroups) return fail(PM_EINVAL, "null argument");
+    FftArgs a = {};
+    a.B = B; a.N = N;
+    int grid = 0, rc;
+    switch (transform) {
+        case 1: rc = fft_launch<1>(a, nullptr, g_fft_frames_per_group, &grid); break;
+        case 2: rc = fft_launch<2>(a, nullptr, g_fft_frames_per_group, &grid); break;
+        case 3: rc = fft_launch<3>(a, nullptr, g_fft_frames_per_group, &grid); break;
+        case 4: rc = fft_launch<4>(a, nullptr, g_fft_frames_per_group, &grid); break;
+        case 5: rc = fft_launch<5>(a, nullptr, g_fft_frames_per_group, &grid); break;
+        default: return fail(PM_EINVAL, "transform must be 1..5");
+    }
+    if (rc) return rc;
+    *total_groups = a.total;
+    *workgroups = grid;
+    return PM_OK;
 }
 
 extern "C" int pm_stft_magnitude(

@@ -185,16 +185,22 @@ struct ElemF16X3 {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
     }
-    // hi = rn(v) saturated at the top of the f16 range, lo = rn(v - hi)
+    // hi = rn(v) saturated at BOTH ends of the f16 range, lo = rn(v - hi),
+    // saturated too: |v| beyond 65504 becomes +-(65504 + 65504) at most, never
+    // an infinity (-inf x a zero-padded weight would be NaN in the MFMA sum).
+    // Two more v_pk_max_f16 per four values in a kernel that issues three
+    // MFMAs per step.
     __device__ static __forceinline__ void split4(
         float4 v, half4& hi, half4& lo) {
         const pm_f4 w = {v.x, v.y, v.z, v.w};
         const _Float16 big = (_Float16)65504.f;
         const half4 top = {big, big, big, big};
-        hi = __builtin_elementwise_min(__builtin_convertvector(w, half4), top);
+        const half4 bottom = {-big, -big, -big, -big};
+        hi = __builtin_elementwise_max(__builtin_elementwise_min(
+            __builtin_convertvector(w, half4), top), bottom);
         const pm_f4 rest = w - __builtin_convertvector(hi, pm_f4);
-        lo = __builtin_elementwise_min(
-            __builtin_convertvector(rest, half4), top);
+        lo = __builtin_elementwise_max(__builtin_elementwise_min(
+            __builtin_convertvector(rest, half4), top), bottom);
     }
     // channels ch .. ch + 3 of an LDS row: the 8-channel group g = ch / 8 is 32
     // bytes, hi parts first; ch % 8 selects the half of both parts

@@ -8,6 +8,20 @@
 
 #include "pm_conv.h"
 
+// Operand types (ElemXX::ID = the PM_* dtype code) whose C = 32 / 64 stages
+// run Block by Block on the skewed walk instead of the fused whole-MRF launch:
+// split f16 (ID 3; three MFMAs per step, so the whole-MRF tiling's 23 % halo
+// recompute shows: profiles/r04/ab_x3_skew.txt) and - measured separately,
+// profiles/r05/ab_x3skew_f32.txt - exact fp32 (ID 0; 16 times the MFMA time per
+// step, the same argument). ONE predicate for the launcher's template choice
+// (pm_launch_block3) and the engine's fusion decision (forward_impl).
+#ifndef PM_X3SKEW_F32
+#define PM_X3SKEW_F32 1
+#endif
+constexpr bool pm_x3skew_id(int id) {
+    return id == 3 || (PM_X3SKEW_F32 && id == 0);
+}
+
 // Opt a kernel into `bytes` of dynamic LDS (> 48 KB needs the attribute).
 // The grant is a property of (kernel, DEVICE): cached per pair, so one process
 // driving several GPUs sets it on each, and guarded so that concurrent
@@ -305,7 +319,7 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
     // MFMA-bound at three MFMAs per step, so what the skew removes - the 23 %
     // halo of the stand-alone whole-MRF tiling - shows: three skewed Block
     // launches 6.07 ms against 6.99 ms fused, profiles/r04/ab_x3_skew.txt)
-    constexpr bool X3SKEW = ET::ESZ == 4 && (C == 32 || C == 64);
+    constexpr bool X3SKEW = pm_x3skew_id(ET::ID) && (C == 32 || C == 64);
     if constexpr ((ET::ESZ == 2 || X3SKEW) && WM * WN == 8 && NTW >= 2) {
         typedef SkewGeom<ET, C, K, WM, WN, NTW> GE;
         static_assert(GE::SCRATCH <= PM_SKEW_WG_SCRATCH, "scratch bound");

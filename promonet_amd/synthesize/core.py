@@ -220,29 +220,35 @@ def from_files_to_files_batched(
     checkpoint: Optional[Union[str, os.PathLike]] = None,
     gpu: Optional[int] = None,
     batch_size: int = 32,
-    num_workers: Optional[int] = None
+    num_workers: Optional[int] = 0
 ) -> None:
     """`from_files_to_files` with the files synthesised `batch_size` at a
     time (sorted by length, zero-padded, ragged-exact) instead of the
     reference's one-utterance loop (synthesize/core.py:158-201). Same files,
     same audio as the sequential path. SURVEY.md 8(f) item 2.
 
-    `num_workers` CPU processes (default: NUM_WORKERS, the size of the pools
-    the reference forks for its file-level preprocessing, defaults.py:387; 0:
-    everything in this process) unpickle the feature files, pad the batches
-    and write the wav files while the GPU synthesises: the serial loop spends
-    three quarters of its time in `torch.load` and the wav writer. The pool is
-    started on first use and kept (`shutdown_workers()` ends it); small jobs
-    (fewer than 4 batches) do not start one and run in this process. As with
-    any `spawn` pool - the reference's included - a calling SCRIPT needs its
+    `num_workers` CPU processes (opt-in; default 0: everything in this
+    process, so that a caller script needs no `if __name__ == '__main__':`
+    guard; `promonet_amd.NUM_WORKERS` = the size of the pools the reference
+    forks for its file-level preprocessing, defaults.py:387, is what the CLI
+    passes) unpickle the feature files, pad the batches and write the wav
+    files while the GPU synthesises: the serial loop spends three quarters of
+    its time in `torch.load` and the wav writer. The pool is started on first
+    use and kept (`shutdown_workers()` ends it; it is keyed on the
+    `configure()` overrides, which the workers re-apply); small jobs (fewer
+    than 4 batches) do not start one and run in this process. As with any
+    `spawn` pool - the reference's included - a calling SCRIPT then needs its
     `if __name__ == '__main__':` guard."""
     device = _device(gpu)
     count = len(pitch_files)
+    if count == 0:
+        return
     if speakers is None:
         speakers = [0] * count
     if num_workers is None:
-        num_workers = promonet_amd.NUM_WORKERS
+        num_workers = 0
     num_workers = min(int(num_workers), os.cpu_count() or 1)
+    hop, rate = promonet_amd.HOPSIZE, promonet_amd.SAMPLE_RATE
     files = (loudness_files, pitch_files, periodicity_files, ppg_files)
     if num_workers < 1 or (count < 4 * batch_size and
                            getattr(_worker_pool, 'pool', None) is None):
@@ -256,7 +262,8 @@ def from_files_to_files_batched(
                 batch, [speakers[i] for i in group], spectral_balance_ratio,
                 loudness_ratio, checkpoint, gpu).cpu()
             _write_group(
-                audio, 0, [output_files[i] for i in group], batch[0])
+                audio, 0, [output_files[i] for i in group], batch[0], hop,
+                rate)
         return
 
     import collections
@@ -276,7 +283,6 @@ def from_files_to_files_batched(
     # once: a tensor pickled to a worker travels as a handle, whereas a fresh
     # 28 MB tensor per batch costs its page faults again in every process
     # (measured: 36 ms per batch, more than its synthesis).
-    hop = promonet_amd.HOPSIZE
     ring = getattr(_worker_pool, 'ring', None)
     if ring is None or ring[0].shape[0] < batch_size or \
             ring[0].shape[-1] < max(lengths) * hop:
@@ -305,17 +311,22 @@ def from_files_to_files_batched(
         audio, done, names, frames = item
         with timer.context('files/wait for writers'):
             for task in busy[slot]:
-                task.get()
+                task.get(WORKER_TIMEOUT)
+            busy[slot] = []
+        rows, width = audio.shape[0], audio.shape[-1]
+        # a CONTIGUOUS (rows, 1, width) view of the slot's first rows x width
+        # floats: a strided destination would make the copy stage through a
+        # fresh pageable buffer (the page faults the ring exists to avoid)
+        target = ring[slot].view(-1)[:rows * width].view(rows, 1, width)
         with timer.context('files/audio to host'):
             copy_stream.wait_event(done)
             with torch.cuda.stream(copy_stream):
-                ring[slot][:audio.shape[0], :, :audio.shape[-1]].copy_(
-                    audio, non_blocking=True)
+                target.copy_(audio, non_blocking=True)
             copy_stream.synchronize()
         busy[slot] = [
             pool.apply_async(_write_group, (
                 ring[slot], first, names[first:first + 8],
-                frames[first:first + 8]))
+                frames[first:first + 8], hop, rate, (rows, width)))
             for first in range(0, len(names), 8)]
 
     upload_stream = torch.cuda.Stream(device)
@@ -333,7 +344,7 @@ def from_files_to_files_batched(
         on the compute stream it would wait for the forward in front of it."""
         refill()
         with timer.context('files/wait for loaders'):
-            batch = loads.popleft().get()
+            batch = loads.popleft().get(WORKER_TIMEOUT)
         ids = [speakers[i] for i in groups[number]]
         _check_speakers(ids)
         with torch.cuda.stream(upload_stream):
@@ -346,31 +357,43 @@ def from_files_to_files_batched(
             ready.record(upload_stream)
         return batch[0], tensors, ready
 
-    staged = upload(0)
-    for number, group in enumerate(groups):
-        frames, tensors, ready = staged
-        compute = torch.cuda.current_stream(device)
-        compute.wait_event(ready)
-        for tensor in tensors:
-            tensor.record_stream(compute)
-        audio = _synthesize_group(
-            (tensors[5], *tensors[:4]), tensors[4], spectral_balance_ratio,
-            loudness_ratio, checkpoint, gpu)
-        done = torch.cuda.Event()
-        done.record(compute)
-        # (the next batch arrives and the previous one leaves the device while
-        # this one computes)
-        if number + 1 < len(groups):
-            staged = upload(number + 1)
+    try:
+        staged = upload(0)
+        for number, group in enumerate(groups):
+            frames, tensors, ready = staged
+            compute = torch.cuda.current_stream(device)
+            compute.wait_event(ready)
+            for tensor in tensors:
+                tensor.record_stream(compute)
+            audio = _synthesize_group(
+                (tensors[5], *tensors[:4]), tensors[4], spectral_balance_ratio,
+                loudness_ratio, checkpoint, gpu)
+            done = torch.cuda.Event()
+            done.record(compute)
+            # (the next batch arrives and the previous one leaves the device
+            # while this one computes)
+            if number + 1 < len(groups):
+                staged = upload(number + 1)
+            if previous is not None:
+                flush(previous, (number - 1) % len(ring))
+            previous = (audio, done, [output_files[i] for i in group], frames)
         if previous is not None:
-            flush(previous, (number - 1) % len(ring))
-        previous = (audio, done, [output_files[i] for i in group], frames)
-    if previous is not None:
-        flush(previous, (len(groups) - 1) % len(ring))
-    with timer.context('files/wait for writers'):
-        for tasks in busy:
-            for task in tasks:
-                task.get()
+            flush(previous, (len(groups) - 1) % len(ring))
+        with timer.context('files/wait for writers'):
+            for tasks in busy:
+                for task in tasks:
+                    task.get(WORKER_TIMEOUT)
+    except BaseException:
+        # writers / loaders of this job may still hold ring slots (or a worker
+        # died: mp.Pool does not notice, hence the timeouts): the next call
+        # must not inherit them - end the pool, drop the ring
+        shutdown_workers()
+        raise
+
+
+# seconds one loader / writer task may take before the job fails instead of
+# hanging on a worker the OS killed (mp.Pool never reports a dead worker)
+WORKER_TIMEOUT = 600.
 
 
 def _worker_pool(num_workers):
@@ -379,26 +402,33 @@ def _worker_pool(num_workers):
     synthesis): cached on the function like the model (`generate.model`),
     replaced when another size is asked for, ended by `shutdown_workers()` or
     at interpreter exit."""
+    overrides = dict(promonet_amd.config.OVERRIDES)
+    key = (num_workers, repr(sorted(overrides.items(), key=lambda kv: kv[0])))
     cached = getattr(_worker_pool, 'pool', None)
-    if cached is not None and cached[0] == num_workers:
+    if cached is not None and cached[0] == key:
         return cached[1]
     shutdown_workers()
     import atexit
     import torch.multiprocessing as mp
     # ('spawn': the children never touch the GPU, but a fork of a process that
     # has initialised HIP inherits its runtime threads' locks)
-    pool = mp.get_context('spawn').Pool(num_workers, initializer=_worker_init)
-    _worker_pool.pool = (num_workers, pool)
+    pool = mp.get_context('spawn').Pool(
+        num_workers, initializer=_worker_init, initargs=(overrides,))
+    _worker_pool.pool = (key, pool)
     if not getattr(_worker_pool, 'registered', False):
         atexit.register(shutdown_workers)
         _worker_pool.registered = True
     return pool
 
 
-def _worker_init():
+def _worker_init(overrides=None):
     # (unpickling and padding are single-threaded work: ten processes with
     # one intra-op thread pool per host core each would only fight)
     torch.set_num_threads(1)
+    # a spawned interpreter imported the package with its DEFAULT constants:
+    # the parent's configure() calls are replayed here
+    if overrides:
+        promonet_amd.configure(**overrides)
 
 
 def shutdown_workers():
@@ -464,14 +494,22 @@ def _synthesize_group(
         loudness_ratio, checkpoint, gpu, lengths=frames)
 
 
-def _write_group(audio, first, output_files, frames):
-    """Rows first ... of the (B, 1, samples) host audio -> one wav per
-    utterance, cut to its length (worker side)."""
+def _write_group(
+    audio, first, output_files, frames, hop=None, sample_rate=None, shape=None
+):
+    """Rows first ... of the host audio -> one wav per utterance, cut to its
+    length (worker side). `audio` is (B, 1, samples), or a ring slot whose
+    first rows x width floats hold a contiguous `shape` = (rows, width) batch.
+    `hop` / `sample_rate` come from the parent: the worker's own module
+    constants are only as good as the overrides replayed into it."""
+    hop = promonet_amd.HOPSIZE if hop is None else hop
+    if shape is not None:
+        rows, width = shape
+        audio = audio.view(-1)[:rows * width].view(rows, 1, width)
     for offset, (file, count) in enumerate(zip(output_files, frames)):
         file = Path(file)
         file.parent.mkdir(exist_ok=True, parents=True)
-        save_audio(
-            file, audio[first + offset, :, :count * promonet_amd.HOPSIZE])
+        save_audio(file, audio[first + offset, :, :count * hop], sample_rate)
 
 
 ###############################################################################
@@ -623,10 +661,11 @@ def set_model(model, device=None):
     generate.device = torch.device(device)
 
 
-def save_audio(file, audio):
+def save_audio(file, audio, sample_rate=None):
     """32-bit float wav, as torchaudio.save writes a float tensor
     (core.py:155)."""
     import scipy.io.wavfile
     scipy.io.wavfile.write(
-        str(file), promonet_amd.SAMPLE_RATE,
+        str(file),
+        promonet_amd.SAMPLE_RATE if sample_rate is None else sample_rate,
         audio.detach().cpu().to(torch.float32).numpy().T.astype(np.float32))

@@ -4,13 +4,15 @@ import pytest
 import torch
 
 import restatement as oracle
-from util import max_abs
+from util import check, max_abs
 
 pytestmark = pytest.mark.gpu
 
 # fp32 math everywhere; f16 / mixed only change the STORAGE of the streamed
-# weights ('mixed': GRU cells and GLU gates f16, the other layers fp32)
-GATE = {'fp32': 5e-6, 'f16': 1e-2, 'mixed': 3e-5}
+# weights ('mixed': GRU cells and GLU gates f16, the other layers fp32).
+# Gates <= 3x what MI355X measures (profiles/r04/pytest_fargan_mixed.log:
+# fp32 3.9e-7, f16 7.6e-5, mixed 6.0e-6 on the reference's goldens)
+GATE = {'fp32': 1.2e-6, 'f16': 2.3e-4, 'mixed': 1.8e-5}
 
 
 @pytest.fixture()
@@ -61,7 +63,7 @@ def test_matches_reference_golden(
         error = max_abs(got, entry['audio'])
         print(f'fargan {dtype} {name}: max-abs {error:.3e} '
               f'(abs-max {entry["audio"].abs().max().item():.3f})')
-        assert error < GATE[dtype], name
+        check(error, GATE[dtype], f'fargan_golden:{dtype}', name)
     model.model.kernel_mode = 0
 
 
@@ -99,13 +101,16 @@ def test_long_sequence_vs_oracle(device, fargan_model):
         want = oracle.fargan_generator_forward(*inputs, fargan_model.state)
         got = model(*on(device, inputs), None)
     assert got.shape == (2, 1, 172 * 256)
-    assert max_abs(got, want) < 2e-5
+    # (measured 3e-7)
+    check(max_abs(got, want), 1e-6, 'fargan_long_sequence:fp32')
 
 
-# whole-utterance max-abs gates: the north star's 1e-4, and for the mixed
-# storage 3x what it measures (6e-6 on the CPU emulation of its rounding,
-# scripts/fargan_weight_sensitivity.py)
-FULL_GATE = {'fp32': 1e-4, 'f16': 1e-4, 'mixed': 2e-5}
+# whole-utterance max-abs gates, <= 3x the measured values (fp32 2.7e-7, f16
+# 6.6e-5, mixed 6.5e-6 over 3 444 dependent steps; three other weight seeds
+# read the same, profiles/r04/fargan_storage_seeds.txt). The north star's 1e-4
+# holds for fp32 and mixed storage with a 15x margin; f16 STORAGE of every
+# weight sits at 0.7 of it, which is why it is not a default.
+FULL_GATE = {'fp32': 1e-6, 'f16': 1e-4, 'mixed': 2e-5}
 _CONFIG5 = {}   # the oracle's audio of the two checked utterances
 
 
@@ -144,7 +149,7 @@ def test_full_size_config5(device, fargan_model, dtype, mode):
     tail = max_abs(got[pick][..., -256 * 40:], want[..., -256 * 40:])
     print(f'fargan full size {dtype} mode {mode}: max-abs {error:.3e} (last 40 '
           f'frames {tail:.3e}; abs-max {want.abs().max().item():.3f})')
-    assert error < FULL_GATE[dtype]
+    check(error, FULL_GATE[dtype], f'fargan_full_size:{dtype}', mode)
 
 
 def test_module_seam(device, fargan_model):
@@ -164,7 +169,7 @@ def test_module_seam(device, fargan_model):
     with torch.inference_mode():
         got = model.model(
             features.to(device), glob.to(device), previous.to(device))
-    assert max_abs(got, want) < 5e-6
+    check(max_abs(got, want), 1.5e-6, 'fargan_module_seam:fp32')
     with pytest.raises(ValueError):
         model.model(features[:, :-1].to(device), glob.to(device), None)
 

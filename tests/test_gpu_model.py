@@ -804,6 +804,25 @@ def test_files_to_files_batched_worker_pipeline(device, default_state, tmp_path)
         assert rate_a == rate_b == 22050
         assert audio_a.shape == audio_b.shape == (length * 256,)
         assert (audio_a == audio_b).all()
+    # configure() overrides reach the spawned workers (a fresh interpreter
+    # imports the package with its defaults): the wav header carries the
+    # parent's SAMPLE_RATE, and the pool is re-keyed on the configuration
+    promonet_amd.configure(SAMPLE_RATE=16000)
+    try:
+        promonet_amd.synthesize.from_files_to_files_batched(
+            *args, files['pool'], speakers=speakers, gpu=0, batch_size=4,
+            num_workers=3)
+        for a, b, length in zip(files['pool'], files['serial'], lengths):
+            rate_a, audio_a = scipy.io.wavfile.read(a)
+            _, audio_b = scipy.io.wavfile.read(b)
+            assert rate_a == 16000
+            assert (audio_a == audio_b).all()
+    finally:
+        promonet_amd.configure(SAMPLE_RATE=22050)
+    # an empty job with a live pool is a no-op
+    promonet_amd.synthesize.from_files_to_files_batched(
+        [], [], [], [], [], gpu=0, num_workers=3)
+    promonet_amd.synthesize.shutdown_workers()
 
 
 def test_packed_interface(device, golden_default, default_state):

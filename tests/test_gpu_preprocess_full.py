@@ -1,0 +1,199 @@
+"""Parity of the STFT / log-mel / loudness kernels ON THE PATH THAT IS
+BENCHMARKED: persistent FFT workgroups that walk several (utterance, frame
+group) pairs each (pm_fft.h: `g += stride`, per-XCD ranges, table and LDS reuse
+across groups, the two loudness passes indexing their per-group maxima alike).
+A workgroup only iterates when there are more groups than resident workgroups
+(occupancy x CUs: 512 for magnitude / log-mel, 768 for the loudness shapes, 256
+with 32 frames per group) - the other preprocess tests stay below that, so every
+test here ASSERTS the geometry through pm_stft_launch_info before it compares.
+
+Reference: promonet/preprocess/spectrogram.py:15-60,111-133,
+promonet/preprocess/loudness.py:17-55,84-111.
+Gates: SURVEY 8(d): STFT / mel 2e-5 abs + 1e-5 rel; loudness 1e-4 dB + 1e-5 rel.
+"""
+import ctypes
+
+import pytest
+import torch
+
+import restatement as oracle
+from util import check
+
+pytestmark = pytest.mark.gpu
+
+# BASELINE.json's workload (batch 32 x 10 s = 861 frames) and a ragged one:
+# B = 3, N % 256 != 0, 301 groups of 16 an utterance -> 903 groups in all
+# (903 % 8 = 7; 453 groups of 32, 453 % 8 = 5)
+FULL = (32, 861 * 256)
+RAGGED = (3, 4811 * 256 + 77)
+SHAPES = {'full': FULL, 'ragged': RAGGED}
+
+
+def geometry(transform, batch, samples):
+    from promonet_amd import _lib
+    total, grid = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().pm_stft_launch_info(
+        transform, batch, samples, ctypes.byref(total), ctypes.byref(grid)))
+    return total.value, grid.value
+
+
+def assert_persistent(transform, batch, samples):
+    """The launch must be the multi-group walk, not one group per workgroup."""
+    total, grid = geometry(transform, batch, samples)
+    assert total > grid >= 256, (transform, total, grid)
+    assert grid % 8 == 0            # the per-XCD ranges of pm_fft.h are taken
+    return total, grid
+
+
+def audio_batch(batch, samples, seed):
+    """Utterances at different levels (each keeps its own max - 80 dB floor),
+    with stretches quiet enough to sit on that floor."""
+    gen = torch.Generator().manual_seed(seed)
+    audio = torch.randn(batch, samples, generator=gen) * .1
+    audio *= (10. ** (-(torch.arange(batch) % 7) / 4.))[:, None]
+    for item in range(batch):
+        start = (item * 7919) % (samples - 4096)
+        audio[item, start:start + 4096] *= 1e-5
+        if item % 3 == 0:
+            audio[item, -2048:] = 0.
+    return audio
+
+
+@pytest.fixture(params=[16, 32])
+def frames_per_group(request):
+    from promonet_amd import _lib
+    _lib.check(_lib.lib().pm_stft_set_frames_per_group(request.param))
+    yield request.param
+    _lib.check(_lib.lib().pm_stft_set_frames_per_group(16))
+
+
+@pytest.fixture(scope='module')
+def cases():
+    """Inputs and oracle results, computed once (27 552 frames of torch.stft
+    and numpy rfft: seconds on the host)."""
+    out = {}
+    for name, (batch, samples) in SHAPES.items():
+        audio = audio_batch(batch, samples, seed=41 if name == 'full' else 43)
+        spec = oracle.spectrogram(audio[:, None])
+        mel = oracle.linear_to_mel(spec)
+        loud = torch.stack([
+            oracle.loudness(audio[item:item + 1], None)
+            for item in range(batch)])
+        out[name] = {'audio': audio, 'spec': spec, 'mel': mel, 'loud': loud}
+    return out
+
+
+def stft_errors(got, want):
+    """(max-abs, worst excess over the 2e-5 + 1e-5 rel gate as a ratio)"""
+    diff = (got.cpu() - want).abs()
+    return diff.max().item(), (diff / (2e-5 + 1e-5 * want.abs())).max().item()
+
+
+@pytest.mark.parametrize('shape', ['full', 'ragged'])
+def test_spectrogram_persistent_walk(device, cases, frames_per_group, shape):
+    import promonet_amd
+    from promonet_amd import _lib
+    batch, samples = SHAPES[shape]
+    total, grid = assert_persistent(1, batch, samples)
+    case = cases[shape]
+    audio = case['audio'].to(device)
+    got = promonet_amd.preprocess.spectrogram.from_audio(audio[:, None])
+    assert got.shape == case['spec'].shape == (batch, 513, samples // 256)
+    error, ratio = stft_errors(got, case['spec'])
+    print(f'stft {shape} fpg {frames_per_group}: {total} groups on {grid} '
+          f'workgroups, max-abs {error:.3e}, worst / gate {ratio:.3f}')
+    check(ratio, 1., f'stft_walk_gate_ratio:{shape}')
+    # twice the same bits (no dependence on which workgroup walked what)
+    again = promonet_amd.preprocess.spectrogram.from_audio(audio[:, None])
+    assert torch.equal(got, again)
+    # the brute-force framed-DFT GEMM: an independent evaluation
+    lib = _lib.lib()
+    size = lib.pm_stft_scratch_bytes(batch, samples)
+    scratch = torch.empty(max(size, 1), dtype=torch.uint8, device=device)
+    dft = torch.empty_like(got)
+    _lib.check(lib.pm_stft_magnitude_dft(
+        _lib.ptr(audio), _lib.ptr(dft), batch, samples, scratch.data_ptr(),
+        scratch.numel(), _lib.stream()))
+    error, ratio = stft_errors(got, dft.cpu())
+    print(f'  vs pm_stft_magnitude_dft: max-abs {error:.3e}, ratio {ratio:.3f}')
+    check(ratio, 1., f'stft_walk_vs_dft_ratio:{shape}')
+
+
+@pytest.mark.parametrize('shape', ['full', 'ragged'])
+def test_log_mel_persistent_walk(device, cases, frames_per_group, shape):
+    import promonet_amd
+    batch, samples = SHAPES[shape]
+    total, grid = assert_persistent(4, batch, samples)
+    case = cases[shape]
+    audio = case['audio'].to(device)
+    fused = promonet_amd.preprocess.spectrogram.from_audio(
+        audio[:, None], mels=True)
+    assert fused.shape == case['mel'].shape == (batch, 80, samples // 256)
+    error, ratio = stft_errors(fused, case['mel'])
+    print(f'log-mel {shape} fpg {frames_per_group}: {total} groups on {grid} '
+          f'workgroups, max-abs {error:.3e}, worst / gate {ratio:.3f}')
+    check(ratio, 1., f'mel_walk_gate_ratio:{shape}')
+    # two-step: the magnitude launch, then pm_linear_to_mel
+    two_step = promonet_amd.preprocess.spectrogram.linear_to_mel(
+        promonet_amd.preprocess.spectrogram.from_audio(audio[:, None]))
+    error, ratio = stft_errors(two_step, case['mel'])
+    check(ratio, 1., f'mel_two_step_gate_ratio:{shape}')
+    check((fused - two_step).abs().max().item(), 2e-5, 'mel_fused_vs_two_step')
+    # the clamp (spectrogram.py:129-132)
+    clamped = promonet_amd.preprocess.spectrogram.from_audio(
+        audio[:, None], mels=True,
+        log_dynamic_range_compression_threshold=-3.)
+    floor = torch.clamp(case['mel'], min=-3.)
+    assert (floor == -3.).any() and (floor > -3.).any()
+    _, ratio = stft_errors(clamped, floor)
+    check(ratio, 1., f'mel_walk_clamped_gate_ratio:{shape}')
+
+
+@pytest.mark.parametrize('shape', ['full', 'ragged'])
+def test_loudness_persistent_walk(device, cases, frames_per_group, shape):
+    """Both passes (per-group maxima, then floored A-weighted band means) at
+    more groups than resident workgroups; every utterance has its own level."""
+    import promonet_amd
+    batch, samples = SHAPES[shape]
+    case = cases[shape]
+    audio = case['audio'].to(device)
+    for bands, second in ((8, 5), (1, 3), (None, 3), (4, 3)):
+        assert_persistent(2, batch, samples)
+        total, grid = assert_persistent(second, batch, samples)
+        want = case['loud'] if bands is None else \
+            oracle.band_average(case['loud'], bands)
+        got = promonet_amd.preprocess.loudness.from_audio(audio, bands)
+        assert got.shape == want.shape
+        diff = (got.cpu() - want).abs()
+        ratio = (diff / (1e-4 + 1e-5 * want.abs())).max().item()
+        print(f'loudness {shape} bands {bands} fpg {frames_per_group}: {total} '
+              f'groups on {grid} workgroups, max-abs {diff.max():.3e} dB, '
+              f'worst / gate {ratio:.3f}')
+        check(ratio, 1., f'loudness_walk_gate_ratio:{shape}:{bands}')
+        again = promonet_amd.preprocess.loudness.from_audio(audio, bands)
+        assert torch.equal(got, again)
+    # (the utterances' levels - hence their max - 80 dB floors - span 30 dB)
+    level = 20. * torch.log10(case['audio'].abs().amax(dim=1))
+    assert level.max() - level.min() > 25.
+
+
+def test_walk_equals_one_group_per_workgroup(device, cases):
+    """Utterance 5 of the full batch alone (54 groups: one per workgroup) is
+    bit-identical to its rows in the walked batch launch - the walk changes
+    the order of the work, never a value."""
+    import promonet_amd
+    audio = cases['full']['audio'].to(device)
+    total, grid = geometry(1, 1, FULL[1])
+    assert total == grid                      # not the walk
+    whole = promonet_amd.preprocess.spectrogram.from_audio(audio[:, None])
+    alone = promonet_amd.preprocess.spectrogram.from_audio(audio[5:6, None])
+    assert torch.equal(whole[5], alone)
+    mel = promonet_amd.preprocess.spectrogram.from_audio(audio[:, None], True)
+    mel_alone = promonet_amd.preprocess.spectrogram.from_audio(
+        audio[5:6, None], True)
+    assert torch.equal(mel[5], mel_alone)
+    for bands in (8, 1, None):
+        loud = promonet_amd.preprocess.loudness.from_audio(audio, bands)
+        loud_alone = promonet_amd.preprocess.loudness.from_audio(
+            audio[5:6], bands)
+        assert torch.equal(loud[5], loud_alone)
