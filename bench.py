@@ -17,6 +17,20 @@ N ranks (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
 --master-addr 127.0.0.1 ...`); under torchrun it uses the environment it is
 given. Other BASELINE.json configs: `--dtype fp32 --batch 8 --seconds 5`
 (config 2), `--model fargan` (config 5).
+
+At N = 1 the line also carries a `secondary` block, measured in the same run
+after the headline region (about 20 s of GPU time; `--no-secondary` skips it):
+the library-default 'checkpoint' operand mode on the headline workload, config
+2 (fp32, 8 x 5 s), config 5 (FARGAN, 'mixed' and 'fp32' weight storage), the
+three preprocess transforms through the C ABI, and the latency of the
+graph-replayed `packed_inference` at nn~ chunk sizes - each with its time, its
+throughput and (where one kernel dominates) that kernel's roofline fraction.
+
+`--stand-in` (tests/test_cpu_bench_multi_rank.py) replaces the HIP engine by a
+trivial torch function so that the N > 1 harness itself - self-launch,
+rendezvous, weight broadcast, GatherPipeline, watchdog, max-over-ranks
+reduction, the `multi_gpu` block - runs on a host without GPUs over gloo. Its
+JSON line says so and is not a measurement.
 """
 import argparse
 import json
@@ -54,10 +68,8 @@ FARGAN_MIXED_F16_WEIGHTS = 3 * 768 * 640 + 5 * 256 * 256
 PEAK_TFLOPS = {'f16': 2500., 'bf16': 2500., 'fp32': 157.3,
                'f16x3': 2500. / 3}
 PEAK_HBM_GBS = 8000.
-# sustained register-resident MFMA rate on random operands under the power cap
-# (scripts/micro/mfma_shapes.hip, profiles/r02/micro_mfma_shapes.txt): what an MFMA
-# kernel can reach on this part; reported beside the nominal peak
-SUSTAINED_TFLOPS = {'f16': 1700., 'bf16': 1900.}
+# (the SUSTAINED rate of the matrix pipe under this device's power cap is
+# measured in the run: mfma_probe below)
 
 
 def parse_args():
@@ -86,6 +98,13 @@ def parse_args():
                              'the HBM traffic of every kernel (roofline.traffic '
                              'then comes from profiles/traffic.json)')
     parser.add_argument('--no-gather', action='store_true')
+    parser.add_argument('--no-secondary', action='store_true',
+                        help='skip the secondary block (checkpoint mode, '
+                             'config 2, FARGAN, preprocess, latency)')
+    parser.add_argument('--stand-in', action='store_true',
+                        help='plumbing test of the N > 1 harness: a trivial '
+                             'torch function instead of the HIP engine (runs '
+                             'without a GPU, over gloo); not a measurement')
     return parser.parse_args()
 
 
@@ -326,6 +345,7 @@ def measure_traffic(args, timeout=150.):
     command = [
         sys.executable, str(Path(__file__).resolve()), '--steps', '1',
         '--warmup', '1', '--sustain', '0', '--no-cpu-baseline', '--no-traffic',
+        '--no-secondary',
         '--model', args.model, '--dtype', args.dtype, '--batch',
         str(args.batch), '--seconds', str(args.seconds)]
     env = dict(os.environ, TMPDIR='/tmp')
@@ -376,6 +396,331 @@ def parse_profile(text):
     return rows
 
 
+class StandIn(torch.nn.Module):
+    """`--stand-in`: what the multi-rank harness needs of a Generator - a
+    parameter to broadcast, a forward that returns (B, 1, 256 T) audio."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.rand(8))
+
+    def forward(self, loudness, pitch, periodicity, ppg, speakers, sbr, lr,
+                previous=None):
+        frame = (pitch * 1e-3 * sbr[:, None] + periodicity + ppg.sum(1) +
+                 loudness.mean(1) * 1e-2 * lr[:, None] +
+                 speakers[:, None] * self.weight.sum())
+        return frame.repeat_interleave(promonet_amd.HOPSIZE, dim=-1)[:, None]
+
+
+def sync(device):
+    if device.type == 'cuda':
+        torch.cuda.synchronize(device)
+
+
+def time_events(fn, reps, warmup=3):
+    """Average milliseconds of `fn` over `reps` back-to-back calls, HIP events
+    on the launch stream (torch's current stream is the one handed to the C
+    ABI)."""
+    for _ in range(warmup):
+        fn()
+    begin = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    begin.record()
+    for _ in range(reps):
+        fn()
+    end.record()
+    end.synchronize()
+    return begin.elapsed_time(end) / reps
+
+
+def mfma_probe(operand, device, target_ms=50.):
+    """The matrix pipe's sustained rate on this device, now: a register-resident
+    loop of v_mfma_f32_32x32x16 (pm_mfma_probe), sized to ~`target_ms`, timed
+    with HIP events. Returns TFLOP/s or None (operand type without a probe)."""
+    code = {'f16': _lib.PM_F16, 'bf16': _lib.PM_BF16, 'f16x3': _lib.PM_F16}.get(
+        operand)
+    if code is None:
+        return None
+    library = _lib.lib()
+    dtype = torch.bfloat16 if code == _lib.PM_BF16 else torch.float16
+    operands = (torch.rand(32768, device=device) * 2 - 1).to(dtype)
+    sink = torch.zeros(1, device=device)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    grid = 2 * cus
+
+    def run(iterations):
+        begin = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        begin.record()
+        _lib.check(library.pm_mfma_probe(
+            code, iterations, operands.data_ptr(), sink.data_ptr(), grid,
+            _lib.stream()))
+        end.record()
+        end.synchronize()
+        return begin.elapsed_time(end)
+    run(200)
+    iterations = 2000
+    ms = run(iterations)
+    iterations = max(200, int(iterations * target_ms / max(ms, 1e-3)))
+    ms = run(iterations)
+    return grid * 4. * iterations * 16 * 32768 / (ms * 1e-3) / 1e12
+
+
+def fargan_roofline(storage, batch, frames, avg_ms, per_gpu_samples_per_s):
+    """FARGAN's `roofline` object from one forward's HIP-event time. What bounds
+    this model is not HBM (0.2 GB of compulsory traffic per launch) nor the
+    matrix pipe (74 kFLOP per sample) but the memory system one level up:
+    every cluster member re-streams its eighth of the weights from its XCD's
+    L2 on each of the 3 444 dependent steps, between 6 inter-workgroup
+    exchanges per step. `achieved` / `peak` are therefore the aggregate L2 ->
+    CU weight stream against the L2's measured 34.5 TB/s
+    (MI355X_MICROARCH.md); the per-step latency of the recurrence stands
+    beside it (its phase breakdown is a profile, not a bench number:
+    profiles/r04/fargan/timeline_fargan.txt)."""
+    steps = frames * 4
+    # ('mixed': the GRU cells and the GLU gates - 1 802 240 of the weights a
+    # sub-frame step streams - are stored f16, the rest fp32)
+    wbytes = {
+        'f16': (FARGAN_STEP_WEIGHTS + FARGAN_COND_WEIGHTS // 4) * 2,
+        'mixed': FARGAN_STEP_WEIGHTS * 4 - FARGAN_MIXED_F16_WEIGHTS * 2,
+    }.get(storage, FARGAN_STEP_WEIGHTS * 4)
+    # a one-utterance cluster member keeps its seven short slices in the LDS
+    # (FgResident, pm_fargan.h: sizes from its static_asserts): not streamed
+    if batch <= 32:
+        wbytes -= 8 * {'mixed': 122_880, 'f16': 102_400}.get(storage, 106_496)
+    # compulsory HBM bytes of one launch: features in, audio out, the weights
+    # once (they stay L2-resident for all 3 444 steps)
+    hbm_bytes = batch * frames * (128 * 4 + 256 * 4) + wbytes
+    clusters = min(32, batch)
+    l2_gbs = wbytes * steps * clusters / (avg_ms * 1e-3) / 1e9
+    return {
+        'kernel': 'pm_fargan_cluster_kernel',
+        # (not an HBM fraction: `achieved` / `peak` / `frac` are the L2 -> CU
+        # weight stream; the recurrence is latency-bound, see latency_model)
+        'bound': 'l2', 'level': 'l2 (weights re-streamed per step)',
+        'achieved': l2_gbs, 'peak': 34500., 'unit': 'GB/s',
+        'frac': l2_gbs / 34500., 'traffic': None,
+        'avg_launch_ms': avg_ms,
+        'algorithmic_bytes_per_launch': hbm_bytes,
+        'hbm_gbs': hbm_bytes / (avg_ms * 1e-3) / 1e9,
+        'note': 'latency-bound recurrence: see latency_model; HBM itself '
+                'carries only hbm_gbs',
+        'latency_model': {
+            'dependent_steps': steps,
+            'us_per_step': avg_ms * 1e3 / steps,
+            'per_cu_l2_stream_gbs': l2_gbs / (clusters * 8),
+            'per_cu_l2_peak_gbs': 34500. / 256,
+            'exchanges_per_step': 6,
+            'matrix_slices_per_step': 13,
+            'tflops': per_gpu_samples_per_s * FARGAN_FLOP_PER_SAMPLE / 1e12}}
+
+
+###############################################################################
+# Secondary block: every other single-GPU claim, measured in the driver's run
+###############################################################################
+
+
+def secondary_hifigan(dtype, batch, seconds, device, steps=6, warmup=2):
+    """One HiFi-GAN configuration: K forwards timed with HIP events, then a
+    per-kernel pass for the dominant kernel and its MFMA fraction."""
+    library = _lib.lib()
+    previous = promonet_amd.COMPUTE_DTYPE
+    promonet_amd.configure(COMPUTE_DTYPE=dtype)
+    try:
+        torch.manual_seed(0)
+        model = promonet_amd.model.Generator().to(device).eval()
+        frames = promonet_amd.convert.seconds_to_frames(seconds)
+        inputs = synthetic_inputs(batch, frames, 1234, device)
+        with torch.inference_mode():
+            ms = time_events(lambda: model(*inputs, None), steps, warmup)
+            engine = model.model.engine()
+            library.pm_hifigan_profile_only(engine, None)
+            library.pm_hifigan_profile_reset(engine)
+            library.pm_hifigan_profile_enable(engine, 1)
+            table_steps = 3
+            for _ in range(table_steps):
+                model(*inputs, None)
+            library.pm_hifigan_profile_enable(engine, 0)
+            library.pm_hifigan_profile_collect(engine)
+            table = parse_profile(
+                library.pm_hifigan_profile_report(engine).decode())
+        label, row = max(table.items(), key=lambda kv: kv[1]['ms'])
+        operand = operand_type_of(label, dtype)
+        launch_ms = row['ms'] / row['launches']
+        tflops = row['flops'] / row['launches'] / (launch_ms * 1e-3) / 1e12
+        samples = batch * frames * promonet_amd.HOPSIZE
+        value = samples / (ms * 1e-3)
+        stem = operand_type_of('input_conv', dtype)
+        return {
+            'workload': f'Generator.forward (prepare_features + HiFi-GAN), '
+                        f'batch {batch} x {seconds:g} s ({frames} frames), '
+                        f'{dtype} MFMA operands, fp32 accumulate',
+            'dtype': dtype, 'batch': batch, 'frames': frames,
+            'steps': steps, 'warmup': warmup,
+            'ms_per_step': ms, 'samples_per_s': value,
+            'rtf': value / promonet_amd.SAMPLE_RATE,
+            'whole_path_tflops': value * FLOP_PER_SAMPLE / 1e12,
+            'whole_path_frac_of_mfma_peak':
+                value * FLOP_PER_SAMPLE / 1e12 / PEAK_TFLOPS[stem],
+            'kernel_ms_per_step':
+                sum(r['ms'] for r in table.values()) / table_steps,
+            'dominant_kernel': {
+                'kernel': label, 'operands': operand,
+                'avg_launch_ms': launch_ms,
+                'launches_per_step': row['launches'] // table_steps,
+                'ms_per_step': row['ms'] / table_steps,
+                'achieved': tflops, 'peak': PEAK_TFLOPS[operand],
+                'unit': 'TFLOP/s', 'bound': 'mfma',
+                'frac': tflops / PEAK_TFLOPS[operand]}}
+    finally:
+        promonet_amd.configure(COMPUTE_DTYPE=previous)
+
+
+def secondary_fargan(storage, device, batch=32, seconds=10., steps=2, warmup=1):
+    """BASELINE.json configs[4]: config/fargan.py, batch 32 x 10 s."""
+    default = promonet_amd.FARGAN_WEIGHT_DTYPE
+    promonet_amd.configure(MODEL='fargan', FARGAN_WEIGHT_DTYPE=storage)
+    try:
+        torch.manual_seed(0)
+        model = promonet_amd.model.Generator().to(device).eval()
+        frames = promonet_amd.convert.seconds_to_frames(seconds)
+        inputs = synthetic_inputs(batch, frames, 1234, device)
+        with torch.inference_mode():
+            ms = time_events(lambda: model(*inputs, None), steps, warmup)
+        samples = batch * frames * promonet_amd.HOPSIZE
+        value = samples / (ms * 1e-3)
+        return {
+            'workload': f'Generator.forward (prepare_features + FARGAN, '
+                        f'config/fargan.py), batch {batch} x {seconds:g} s '
+                        f'({frames} frames = {frames * 4} dependent sub-frame '
+                        f'steps), weights stored as {storage}, fp32 arithmetic',
+            'weight_storage': storage,
+            'library_default_storage': storage == default,
+            'dtype': 'fp32', 'steps': steps, 'warmup': warmup,
+            'ms_per_step': ms, 'samples_per_s': value,
+            'rtf': value / promonet_amd.SAMPLE_RATE,
+            'dominant_kernel': fargan_roofline(
+                storage, batch, frames, ms, value)}
+    finally:
+        promonet_amd.configure(MODEL='hifigan', FARGAN_WEIGHT_DTYPE=default)
+
+
+def secondary_preprocess(device, batch=32, seconds=10., reps=50):
+    """spectrogram.from_audio, from_audio(mels=True) and loudness.from_audio
+    (8 bands) of `batch` x `seconds` of audio through the C ABI on
+    preallocated buffers (spectrogram.py:15-60,111-133; loudness.py:17-55):
+    HBM-bound streaming kernels, algorithmic bytes = 4 B / sample in (twice
+    for the two loudness passes) + 4 B per output value."""
+    library = _lib.lib()
+    frames = promonet_amd.convert.seconds_to_frames(seconds)
+    samples = frames * promonet_amd.HOPSIZE
+    bins = promonet_amd.NUM_FFT // 2 + 1
+    mels = promonet_amd.NUM_MELS
+    gen = torch.Generator().manual_seed(1234)
+    audio = (torch.randn(batch, samples, generator=gen) * .1).to(device)
+    spec = torch.empty(batch, bins, frames, device=device)
+    mel = torch.empty(batch, mels, frames, device=device)
+    loud = torch.empty(batch, 8, frames, device=device)
+    weights = promonet_amd.preprocess.loudness.perceptual_weights_tensor(device)
+    prepared = promonet_amd.preprocess.spectrogram._prepared_mel_basis(device)
+    scratch = torch.empty(
+        max(1, library.pm_loudness_scratch_bytes(batch, samples)),
+        dtype=torch.uint8, device=device)
+    stream = _lib.stream()
+    calls = {
+        'spectrogram': (lambda: _lib.check(library.pm_stft_magnitude(
+            _lib.ptr(audio), _lib.ptr(spec), batch, samples, None, 0, stream)),
+            4. * batch * samples + 4. * spec.numel(), 1),
+        'log_mel': (lambda: _lib.check(library.pm_stft_mel(
+            _lib.ptr(audio), prepared.data_ptr(), _lib.ptr(mel), batch,
+            samples, mels, 0, 0., stream)),
+            4. * batch * samples + 4. * mel.numel(), 1),
+        'loudness_8_bands': (lambda: _lib.check(library.pm_loudness(
+            _lib.ptr(audio), _lib.ptr(weights), _lib.ptr(loud), batch, samples,
+            8, float(promonet_amd.MIN_DB), scratch.data_ptr(), scratch.numel(),
+            stream)),
+            2 * 4. * batch * samples + 4. * loud.numel(), 2)}
+    out = {
+        'workload': f'{batch} x {seconds:g} s of audio ({frames} frames each) '
+                    'through the C ABI, buffers preallocated',
+        'dtype': 'fp32', 'reps': reps}
+    for name, (call, nbytes, launches) in calls.items():
+        ms = time_events(call, reps, warmup=5)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {
+            'ms': ms, 'kernel_launches': launches,
+            'audio_seconds_per_second': batch * seconds / (ms * 1e-3),
+            'algorithmic_bytes': nbytes, 'bound': 'hbm',
+            'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+            'frac': gbs / PEAK_HBM_GBS}
+    return out
+
+
+def secondary_latency(device, chunks=(8, 16, 32, 64), reps=200):
+    """The streaming (nn~) use of the generator, generator.py:334-343:
+    `packed_inference` on one (1, 53, T) buffer, eager and as a replayed
+    hipGraph (`graph=True`), host wall-clock per call including the sync."""
+    promonet_amd.configure(COMPUTE_DTYPE=promonet_amd.DEFAULT_COMPUTE_DTYPE)
+    torch.manual_seed(0)
+    model = promonet_amd.model.Generator().to(device).eval()
+    out = {'workload': 'Generator.packed_inference, batch 1, '
+                       f'{promonet_amd.DEFAULT_COMPUTE_DTYPE} operand mode, host '
+                       'wall-clock per call (submit + synchronize), median',
+           'reps': reps}
+    gen = torch.Generator().manual_seed(7)
+    with torch.inference_mode():
+        for frames in chunks:
+            packed = torch.rand(1, 53, frames, generator=gen).to(device)
+            row = {}
+            for name, kwargs in (('eager', {}), ('graph', {'graph': True})):
+                for _ in range(5):
+                    model.packed_inference(packed, **kwargs)
+                torch.cuda.synchronize()
+                times = []
+                for _ in range(reps):
+                    begin = time.perf_counter()
+                    model.packed_inference(packed, **kwargs)
+                    torch.cuda.synchronize()
+                    times.append(time.perf_counter() - begin)
+                row[f'{name}_us'] = statistics.median(times) * 1e6
+            chunk_seconds = frames * promonet_amd.HOPSIZE / promonet_amd.SAMPLE_RATE
+            row['chunk_ms_of_audio'] = chunk_seconds * 1e3
+            row['graph_rtf'] = chunk_seconds / (row['graph_us'] * 1e-6)
+            out[f'frames_{frames}'] = row
+    return out
+
+
+def secondary_block(device, budget=45.):
+    """Every single-GPU claim besides the headline, on this run's clock. An
+    entry that fails reports its error instead of taking the line down; an
+    entry that would start past `budget` seconds is skipped and says so."""
+    plan = [
+        ('hifigan_checkpoint_batch32_10s',
+         lambda: secondary_hifigan('checkpoint', 32, 10., device)),
+        ('hifigan_fp32_config2_batch8_5s',
+         lambda: secondary_hifigan('fp32', 8, 5., device)),
+        ('fargan_mixed_batch32_10s', lambda: secondary_fargan('mixed', device)),
+        ('fargan_fp32_batch32_10s', lambda: secondary_fargan('fp32', device)),
+        ('preprocess_batch32_10s', lambda: secondary_preprocess(device)),
+        ('packed_inference_latency', lambda: secondary_latency(device))]
+    out = {}
+    begin = time.perf_counter()
+    for name, run in plan:
+        spent = time.perf_counter() - begin
+        if spent > budget:
+            out[name] = {'skipped': f'{spent:.0f} s of the {budget:.0f} s '
+                                    'secondary budget already spent'}
+            continue
+        try:
+            out[name] = run()
+        except Exception as error:        # noqa: BLE001 (reported, not fatal)
+            out[name] = {'error': f'{type(error).__name__}: {error}'}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    out['seconds'] = time.perf_counter() - begin
+    return out
+
+
 def main():
     args = parse_args()
     if args.dtype is None:
@@ -397,9 +742,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(
             f'bench.py: WORLD_SIZE {world} != --gpus {args.gpus}')
-    if not torch.cuda.is_available():
+    stand_in = args.stand_in
+    if not torch.cuda.is_available() and not stand_in:
         raise RuntimeError('bench.py needs an AMD GPU')
-    fargan = args.model == 'fargan'
+    fargan = args.model == 'fargan' and not stand_in
+    hifigan = not fargan and not stand_in
 
     frames = promonet_amd.convert.seconds_to_frames(args.seconds)
     samples_per_step = args.batch * frames * promonet_amd.HOPSIZE
@@ -407,16 +754,19 @@ def main():
     if fargan:
         weight_dtype = args.dtype if args.dtype in ('f16', 'mixed') else 'fp32'
         promonet_amd.configure(MODEL='fargan', FARGAN_WEIGHT_DTYPE=weight_dtype)
-    else:
+    elif hifigan:
         promonet_amd.configure(COMPUTE_DTYPE=args.dtype)
-    torch.manual_seed(0)
-    model = promonet_amd.model.Generator().to(device).eval()
+    # (every rank starts from its OWN weights: what makes them equal is the
+    # broadcast below, as in the job that loads a checkpoint on rank 0)
+    torch.manual_seed(rank if world > 1 else 0)
+    model = (StandIn() if stand_in else promonet_amd.model.Generator()).to(
+        device).eval()
     if world > 1:
         watchdog.arm('weight broadcast')
     promonet_amd.distributed.broadcast_model(model)     # RCCL broadcast
     inputs = synthetic_inputs(args.batch, frames, 1234 + rank, device)
     gather = world > 1 and not args.no_gather
-    backend = dist.get_backend() if world > 1 else None
+    backend = promonet_amd.distributed.backend() if world > 1 else None
     # N > 1: the all-gather of step k runs on RCCL's stream while step k + 1
     # computes (promonet_amd.distributed.GatherPipeline: two destination
     # buffers, every collective waited for inside the timed region)
@@ -437,12 +787,12 @@ def main():
 
     def fence():
         drain()
-        torch.cuda.synchronize()
+        sync(device)
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+            dist.barrier()          # (the gloo control group)
+            sync(device)
 
-    library = _lib.lib()
+    library = None if stand_in else _lib.lib()
     engine = None
     forward_events = []
     def guarded(what):
@@ -459,7 +809,7 @@ def main():
         for _ in range(args.warmup):
             step()
         kernel_table = None
-        if not fargan:
+        if hifigan:
             # Per-kernel table: a separate pass of K steps with HIP events
             # around EVERY launch (not part of `value`: 34 event pairs per step
             # cost 0.7 % of it). The timed region then brackets only the
@@ -498,7 +848,7 @@ def main():
                 step()
         fence()
         elapsed = time.perf_counter() - start
-        if not fargan:
+        if hifigan:
             library.pm_hifigan_profile_enable(engine, 0)
             library.pm_hifigan_profile_collect(engine)
             timed_profile = parse_profile(
@@ -512,6 +862,12 @@ def main():
             per_step = max(elapsed / args.steps, 1e-4)
             count = max(args.steps, int(math.ceil(args.sustain / per_step)))
             count = min(count, int(60. / per_step) + 1)
+            if world > 1:
+                # every rank must run the SAME number of steps (each one is a
+                # collective): rank 0's count, not one from each rank's clock
+                agreed = torch.tensor([count], dtype=torch.int64)
+                dist.broadcast(agreed, src=0)
+                count = int(agreed.item())
             fence()
             guarded('sustained loop')
             begin = time.perf_counter()
@@ -530,7 +886,7 @@ def main():
             begin = time.perf_counter()
             for _ in range(args.steps):
                 audio = model(*inputs, None)
-            torch.cuda.synchronize()
+            sync(device)
             compute_own = time.perf_counter() - begin
             fence()
             gather_alone = 0.
@@ -546,13 +902,13 @@ def main():
 
     if world > 1:
         watchdog.arm('timing reduction')
+        # (host doubles over the gloo control group)
         own = torch.tensor(
             [elapsed, sustained[0] if sustained else 0., diagnosis[0],
-             diagnosis[1]], dtype=torch.float64, device=device)
-        own = own.cpu() if backend == 'gloo' else own
+             diagnosis[1]], dtype=torch.float64)
         every = [torch.empty_like(own) for _ in range(world)]
         dist.all_gather(every, own)
-        every = torch.stack([t.cpu() for t in every])        # (world, 4)
+        every = torch.stack(every)                            # (world, 4)
         rank_step_ms = (every[:, 0] / args.steps * 1e3).tolist()
         rank_compute_ms = (every[:, 2] / args.steps * 1e3).tolist()
         elapsed = every[:, 0].max().item()
@@ -573,6 +929,11 @@ def main():
                 f'per GPU ({frames} frames = {frames * 4} dependent sub-frame '
                 f'steps), random-init weights stored as '
                 f'{promonet_amd.FARGAN_WEIGHT_DTYPE}, fp32 arithmetic')
+        elif stand_in:
+            workload = (
+                f'STAND-IN torch function (not the HIP engine): plumbing test '
+                f'of the {world}-rank harness, batch {args.batch} x '
+                f'{args.seconds:g} s per rank - NOT a measurement')
         else:
             workload = (
                 f'Generator.forward (prepare_features + HiFi-GAN), '
@@ -606,20 +967,25 @@ def main():
                 'test_full_size_every_sample); at trained-checkpoint scale see '
                 'DESIGN.md section 3 - the library default is the split-f16 '
                 "'checkpoint' mode (--dtype checkpoint)"),
-            'data': 'synthetic',
+            'data': 'synthetic' if not stand_in else
+                    'synthetic; stand-in model (plumbing test, invalid as a '
+                    'measurement)',
             'config': {
                 'workload': workload,
                 'model': args.model,
                 'batch_per_gpu': args.batch,
                 'frames': frames,
                 'backend': backend,
-                'devices': torch.cuda.device_count(),
+                'devices': torch.cuda.device_count()
+                           if torch.cuda.is_available() else 0,
                 'parallelism': f'batch-sharded x{world}' + (
                     ' + RCCL all-gather of audio (overlapped with the next '
                     'step, drained inside the timed region)' if overlap else
                     ' + all-gather of audio staged through host memory over '
-                    'gloo (more ranks than GPUs: test-box mode)' if gather
-                    else '')},
+                    'gloo (ranks share a GPU: test-box mode, NOT a scaling '
+                    'measurement)' if gather and device.type == 'cuda' else
+                    ' + all-gather of audio over gloo (host tensors)'
+                    if gather else '')},
             'rtf': value / promonet_amd.SAMPLE_RATE,
             'samples_per_sec_per_gpu': per_gpu,
             'rtf_per_gpu': per_gpu / promonet_amd.SAMPLE_RATE,
@@ -634,7 +1000,15 @@ def main():
                 pass
             result['multi_gpu'] = {
                 'world_size_reported_by_backend': dist.get_world_size(),
+                # data plane (weight broadcast, audio all-gather): 'nccl' =
+                # RCCL when every rank owns a GPU; the control plane
+                # (barriers, this timing reduction) is always gloo
                 'backend': backend,
+                'control_plane_backend': dist.get_backend(),
+                'ranks_share_a_device': promonet_amd.distributed.folded(),
+                'gloo_fallback': promonet_amd.distributed._STATE['note'],
+                # what every rank bound: device index, PCI / UUID identity
+                'devices': promonet_amd.distributed.rank_devices(),
                 'rccl_version': rccl,
                 'compute_ms_per_step': compute_ms,
                 'gather_alone_ms_per_step': gather_ms,
@@ -654,75 +1028,12 @@ def main():
                 world * samples_per_step * count / seconds
         if fargan:
             times = [a.elapsed_time(b) for a, b in forward_events]
-            avg_ms = sum(times) / len(times)
-            steps = frames * 4
-            # ('mixed': the GRU cells and the GLU gates - 1 802 240 of the
-            # weights a sub-frame step streams - are stored f16, the rest fp32)
-            storage = promonet_amd.FARGAN_WEIGHT_DTYPE
-            wbytes = {
-                'f16': (FARGAN_STEP_WEIGHTS + FARGAN_COND_WEIGHTS // 4) * 2,
-                'mixed': FARGAN_STEP_WEIGHTS * 4 - FARGAN_MIXED_F16_WEIGHTS * 2,
-            }.get(storage, FARGAN_STEP_WEIGHTS * 4)
-            # a one-utterance cluster member keeps its seven short slices in
-            # the LDS (FgResident, pm_fargan.h: 2-byte gate storage): those are
-            # not streamed from the L2
-            # (all-fp32 storage: the three GRU gates and the output layer)
-            resident = args.batch <= 32
-            if resident:
-                wbytes -= 8 * {'mixed': 122_880, 'f16': 102_400}.get(
-                    storage, 106_496)
-            # compulsory HBM bytes of one launch: features in, audio out, the
-            # weights once (they stay L2-resident for all 3 444 steps)
-            hbm_bytes = args.batch * frames * (128 * 4 + 256 * 4) + wbytes
-            clusters = min(32, args.batch)
-            # What bounds this model is not HBM (0.2 GB of compulsory traffic
-            # per launch) nor the matrix pipe (74 kFLOP per sample) but the
-            # memory system one level up: every cluster member re-streams its
-            # eighth of the weights from its XCD's L2 on each of the 3 444
-            # dependent steps, between 6 inter-workgroup exchanges per step.
-            # `achieved` / `peak` are therefore the aggregate L2 -> CU weight
-            # stream against the L2's measured 34.5 TB/s
-            # (MI355X_MICROARCH.md); the latency floor of the recurrence
-            # stands beside it.
-            l2_gbs = wbytes * steps * clusters / (avg_ms * 1e-3) / 1e9
-            us_per_step = avg_ms * 1e3 / steps
-            # What a step is made of (phase timeline of this build,
-            # profiles/r04/fargan/timeline_fargan.txt: member 1 of cluster 0,
-            # one sub-frame step, shader-clock cycles): the six inter-workgroup
-            # exchanges - a write-through store and an sc1 load to the memory
-            # side of the L2s and back, with the known-early weight products
-            # streamed in between - are 60 % of it, the 13 matrix slices on
-            # the dependency chain (reduced inside a wave) and the activations
-            # the rest. The earlier rounds' "26 us latency floor" model (1.1
-            # us per slice for two barriers, an LDS reduction and an L2 round
-            # trip) described a step this build no longer runs.
-            exchange_share = 0.60
-            result['roofline'] = {
-                'kernel': 'pm_fargan_cluster_kernel',
-                # (not an HBM fraction: `achieved` / `peak` / `frac` are the L2
-                # -> CU weight stream; the recurrence is latency-bound, see
-                # latency_model)
-                'bound': 'l2', 'level': 'l2 (weights re-streamed per step)',
-                'achieved': l2_gbs,
-                'peak': 34500., 'unit': 'GB/s',
-                'frac': l2_gbs / 34500.,
-                'traffic': None,
-                'avg_launch_ms': avg_ms,
-                'algorithmic_bytes_per_launch': hbm_bytes,
-                'hbm_gbs': hbm_bytes / (avg_ms * 1e-3) / 1e9,
-                'note': 'latency-bound recurrence: see latency_model; HBM '
-                        'itself carries only hbm_gbs',
-                'latency_model': {
-                    'dependent_steps': steps,
-                    'us_per_step': us_per_step,
-                    'per_cu_l2_stream_gbs': l2_gbs / (clusters * 8),
-                    'per_cu_l2_peak_gbs': 34500. / 256,
-                    'exchanges_per_step': 6,
-                    'matrix_slices_per_step': 13,
-                    'exchange_share_of_step': exchange_share,
-                    'exchange_share_source':
-                        'profiles/r04/fargan/timeline_fargan.txt',
-                    'tflops': per_gpu * FARGAN_FLOP_PER_SAMPLE / 1e12}}
+            result['roofline'] = fargan_roofline(
+                promonet_amd.FARGAN_WEIGHT_DTYPE, args.batch, frames,
+                sum(times) / len(times), per_gpu)
+        elif stand_in:
+            result['stand_in'] = True
+            result['roofline'] = None
         else:
             # dominant kernel family: HIP events around its launches, on the
             # launch stream, inside the timed region; every other kernel's row
@@ -741,6 +1052,14 @@ def main():
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             traffic, measured_step_bytes, covered_ms = None, None, 0.
             operand = operand_type_of(label, args.dtype)
+            sustained_peak = None
+            if world == 1:
+                try:
+                    sustained_peak = mfma_probe(operand, device)
+                    if sustained_peak and operand == 'f16x3':
+                        sustained_peak /= 3.     # per USEFUL flop
+                except Exception as error:          # noqa: BLE001
+                    sys.stderr.write(f'bench.py: mfma probe failed: {error}\n')
             table, traffic_source = None, None
             if not args.no_traffic and world == 1:
                 table, traffic_source = measure_traffic(args)
@@ -777,10 +1096,14 @@ def main():
                 'frac': achieved / PEAK_TFLOPS[operand],
                 'traffic': traffic,
                 'traffic_source': traffic_source if traffic else None,
-                'sustained_peak': SUSTAINED_TFLOPS.get(operand),
+                # the matrix pipe's rate on a register-resident loop of the same
+                # MFMA instruction, measured in THIS run right after the timed
+                # steps (pm_mfma_probe, ~50 ms): what the power cap leaves
+                'sustained_peak': sustained_peak,
+                'sustained_peak_source': 'pm_mfma_probe in this run'
+                                         if sustained_peak else None,
                 'frac_of_sustained_peak': (
-                    achieved / SUSTAINED_TFLOPS[operand]
-                    if operand in SUSTAINED_TFLOPS else None),
+                    achieved / sustained_peak if sustained_peak else None),
                 'avg_launch_ms': avg_ms,
                 'launches_per_step': row['launches'] // args.steps,
                 'algorithmic_flops_per_launch': flops_per_launch,
@@ -828,14 +1151,19 @@ def main():
                     'tflops': v['flops'] / max(v['ms'], 1e-9) / 1e9,
                     'gbs': v['bytes'] / max(v['ms'], 1e-9) / 1e6}
                 for k, v in sorted(profile.items())}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not stand_in and not args.no_secondary:
+            # (the headline model's workspace goes back to the allocator first)
+            del model, inputs
+            torch.cuda.empty_cache()
+            result['secondary'] = secondary_block(device)
+        if world == 1 and not stand_in and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.model)
         print(json.dumps(result))
 
     if world > 1:
         watchdog.arm('final barrier')
         dist.barrier()
-        dist.destroy_process_group()
+        promonet_amd.distributed.shutdown()
     watchdog.disarm()
 
 

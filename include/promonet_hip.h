@@ -286,6 +286,13 @@ int pm_debug_force(int walk_nseg, int upsample_groups);
  * default (the shapes it measured faster on). Per host thread, and only
  * with PROMONET_HIP_DEBUG=1, like pm_debug_force.                           */
 int pm_debug_skew(int mode);
+/* Measurement aid (bench.py): a register-resident loop of v_mfma_f32_32x32x16
+ * (dtype PM_F16 | PM_BF16) - `workgroups` x 4 waves x `iterations` x 16 MFMAs
+ * of 32 768 FLOP each - whose HIP-event time gives the matrix pipe's SUSTAINED
+ * rate on this device under its power cap. operands: >= 65 536 bytes of finite
+ * values of that type; sink: 4 bytes (never written).                       */
+int pm_mfma_probe(int dtype, int iterations, const void* operands,
+                  float* sink, int workgroups, void* stream);
 /* Scratch the skewed whole-Block walk wants BEHIND the 3 x
  * pm_op_workspace_bytes() of pm_block_cl's workspace for `batch` utterances
  * (optional: without it the walked / stand-alone kernels run). The engine's

@@ -77,6 +77,7 @@ SIGNATURES = {
     'pm_debug_timeline': (_I, [_P]),
     'pm_debug_force': (_I, [_I, _I]),
     'pm_debug_skew': (_I, [_I]),
+    'pm_mfma_probe': (_I, [_I, _I, _P, _P, _I, _P]),
     'pm_walk_scratch_bytes': (_S, [_I]),
     'pm_fold_weight_norm': (_I, [_P, _P, _P, _I, _I, _P]),
     'pm_to_channels_last': (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -1429,6 +1429,28 @@ extern "C" int pm_debug_force(int walk_nseg, int upsample_groups) {
 // Test hook: -1 keeps the launchers off the skewed whole-Block walk, 1 takes
 // it wherever it fits, 0 restores the default (the shapes it measured faster
 // on, when scratch was handed over).
+// Sustained-rate probe of the matrix pipe (bench.py times it with HIP events
+// on `stream`): `workgroups` x 4 waves x `iterations` x 16 MFMAs of 32 768 FLOP.
+// operands: >= 65 536 bytes of finite values of the operand type.
+extern "C" int pm_mfma_probe(int dtype, int iterations, const void* operands,
+                             float* sink, int workgroups, void* stream) {
+    if (!operands || !sink) return fail(PM_EINVAL, "null argument");
+    if (iterations < 1 || workgroups < 1)
+        return fail(PM_EINVAL, "bad probe arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const uint4* src = (const uint4*)operands;
+    if (dtype == PM_F16)
+        hipLaunchKernelGGL(pm_mfma_probe_kernel<1>, dim3(workgroups), dim3(256),
+                           0, s, src, sink, iterations);
+    else if (dtype == PM_BF16)
+        hipLaunchKernelGGL(pm_mfma_probe_kernel<2>, dim3(workgroups), dim3(256),
+                           0, s, src, sink, iterations);
+    else
+        return fail(PM_EINVAL, "probe operand type must be PM_F16 or PM_BF16");
+    HIP_TRY(hipGetLastError());
+    return PM_OK;
+}
+
 extern "C" int pm_debug_skew(int mode) {
     if (!debug_hooks_enabled())
         return fail(PM_ESTATE, "debug hooks are disabled "

@@ -667,3 +667,45 @@ __global__ __launch_bounds__(256) void pm_stretch_grid_kernel(StretchArgs a) {
         a.grid[j] = position;
     }
 }
+
+// Sustained MFMA rate probe (pm_mfma_probe): 4 x 4 independent 32x32x16
+// MFMAs per iteration and wave on register-resident operands - what the matrix
+// pipe holds on THIS device under ITS power cap, measured beside the bench's
+// kernels instead of quoted from an earlier round. KIND 1: f16, 2: bf16.
+template <int KIND>
+__global__ __launch_bounds__(256) void pm_mfma_probe_kernel(
+    const uint4* __restrict__ src, float* __restrict__ sink, int iters) {
+    uint4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = src[(threadIdx.x + 256 * i) & 4095];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = src[(threadIdx.x + 256 * (i + 4)) & 4095];
+    floatx16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (KIND == 1)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(half8, a[k]),
+                        __builtin_bit_cast(half8, b[i]), acc[i], 0, 0, 0);
+                else
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, a[k]),
+                        __builtin_bit_cast(bf16x8, b[i]), acc[i], 0, 0, 0);
+            }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) sink[0] = s;
+}
+

@@ -10,21 +10,89 @@ the path shards on the batch axis with replicated weights:
 same code over "gloo" with a stand-in synthesis function.
 """
 import os
+import socket
+import sys
 
 import torch
 import torch.distributed as dist
+
+# What init() decided. The DEFAULT process group is always gloo: the control
+# plane (barriers, timing reductions, the device-identity exchange below) moves
+# a few bytes of host memory and must work whatever the GPUs do. The DATA plane
+# (weight broadcast, audio all-gather) is a second group over RCCL ("nccl")
+# when every rank owns a physical GPU of its own, and the default gloo group -
+# device tensors staged through host memory - when ranks share one (a 1-GPU
+# test box running the 2-rank path).
+_STATE = {
+    'group': None,        # data-plane group (None: the default group)
+    'backend': None,      # 'nccl' | 'gloo' of the data plane
+    'folded': False,      # ranks share a physical device
+    'devices': None,      # per rank: {'rank', 'host', 'index', 'id', 'name'}
+    'note': None}
+
+
+def backend():
+    """Backend of the data plane: 'nccl' (= RCCL), 'gloo', or None."""
+    return _STATE['backend'] if dist.is_initialized() else None
+
+
+def data_group():
+    return _STATE['group']
+
+
+def rank_devices():
+    """What every rank runs on (rank, host, device index, PCI identity), as
+    exchanged at init - the `multi_gpu.devices` block of bench.py."""
+    return _STATE['devices']
+
+
+def folded():
+    return bool(_STATE['folded'])
+
+
+def device_identity(index):
+    """A string that names the PHYSICAL device behind cuda:`index` of this
+    process: its UUID / PCI address where torch exposes them, else the
+    visibility mask + index (two ranks that each see one isolated GPU as
+    cuda:0 must not look like two ranks on one GPU)."""
+    props = torch.cuda.get_device_properties(index)
+    parts = []
+    uuid = getattr(props, 'uuid', None)
+    if uuid is not None and set(str(uuid)) - set('0-'):
+        parts.append(f'uuid:{uuid}')
+    pci = [getattr(props, name, None) for name in (
+        'pci_domain_id', 'pci_bus_id', 'pci_device_id')]
+    if any(value is not None for value in pci):
+        parts.append('pci:' + ':'.join(
+            '?' if value is None else f'{value:02x}' for value in pci))
+    if not parts:
+        mask = ','.join(
+            os.environ.get(name, '') for name in (
+                'ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES',
+                'CUDA_VISIBLE_DEVICES'))
+        parts.append(f'visible[{mask}]:{index}')
+    return ' '.join(parts)
 
 
 def init(backend=None, force=False, timeout=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE /
     LOCAL_RANK / MASTER_ADDR / MASTER_PORT). Returns (rank, world, device).
-    `force` creates the process group for a single rank too (a 1-GPU box can
+    `force` creates the process groups for a single rank too (a 1-GPU box can
     then drive RCCL's collectives, asynchronous overlap included).
 
-    One rank per GPU over RCCL ("nccl"). When there are more local ranks than
-    GPUs (a 1-GPU test box running the 2-rank path) the ranks fold onto the
-    devices round-robin and the backend falls back to gloo - RCCL refuses two
-    ranks on one device - with the collectives staged through host memory.
+    One rank per GPU, data plane over RCCL ("nccl"). Which it is gets DECIDED
+    FROM THE DEVICES, not from rank arithmetic: every rank publishes the
+    physical identity of the GPU it bound (over the gloo control group) and
+      * all different -> RCCL;
+      * some equal and more local ranks than visible GPUs (LOCAL_WORLD_SIZE >
+        device_count: a 1-GPU test box running the 2-rank path) -> the ranks
+        stay folded, the data plane falls back to gloo staged through host
+        memory, and every rank says so on stderr - such a run exercises the
+        plumbing, its timings are NOT a scaling measurement;
+      * some equal although every local rank could have had its own GPU (a
+        mis-set LOCAL_RANK) -> RuntimeError: a scaling run must not silently
+        become a host-staged one.
+    `backend` (or PROMONET_DIST_BACKEND) forces the data plane's backend.
     `timeout` (seconds; default: torch's 10 / 30 minutes) bounds every
     collective: a rank that never arrives fails the job instead of hanging it."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -40,22 +108,70 @@ def init(backend=None, force=False, timeout=None):
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        folded = use_gpu and local_world > devices
-        backend = backend or os.environ.get('PROMONET_DIST_BACKEND') or (
-            'nccl' if use_gpu and not folded else 'gloo')
         extra = {}
         if timeout is not None:
             import datetime
             extra['timeout'] = datetime.timedelta(seconds=float(timeout))
-        dist.init_process_group(backend, rank=rank, world_size=world, **extra)
+        dist.init_process_group('gloo', rank=rank, world_size=world, **extra)
+        mine = {
+            'rank': rank, 'host': socket.gethostname(), 'index': index,
+            'id': device_identity(index) if use_gpu else 'cpu',
+            'name': torch.cuda.get_device_name(index) if use_gpu else 'cpu'}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        owners = {}
+        for entry in every:
+            owners.setdefault((entry['host'], entry['id']), []).append(
+                entry['rank'])
+        shared = {k: v for k, v in owners.items() if len(v) > 1} \
+            if use_gpu else {}
+        wanted = backend or os.environ.get('PROMONET_DIST_BACKEND')
+        note = None
+        if shared and wanted != 'gloo':
+            text = '; '.join(
+                f'ranks {ranks} on {host} share {ident}'
+                for (host, ident), ranks in sorted(shared.items()))
+            if wanted == 'nccl':
+                raise RuntimeError(
+                    f'promonet_amd.distributed.init: backend nccl asked for '
+                    f'but {text} (RCCL refuses two ranks on one device)')
+            if local_world <= devices:
+                raise RuntimeError(
+                    f'promonet_amd.distributed.init: {text} although '
+                    f'{devices} GPUs are visible for {local_world} local '
+                    'ranks - LOCAL_RANK mis-set? Refusing to fall back to '
+                    'host-staged gloo collectives for a job that could run '
+                    'one rank per GPU over RCCL.')
+            note = (
+                f'{text}: {local_world} local ranks on {devices} visible '
+                'GPU(s) - data plane over gloo, staged through host memory '
+                '(test-box mode; NOT a scaling measurement)')
+            sys.stderr.write(
+                f'promonet_amd.distributed [rank {rank}]: WARNING: {note}\n')
+            sys.stderr.flush()
+        chosen = wanted or ('nccl' if use_gpu and not shared else 'gloo')
+        group = None
+        if chosen == 'nccl':
+            group = dist.new_group(backend='nccl', **extra)
+        elif chosen != 'gloo':
+            raise ValueError(f'unknown backend {chosen}')
+        _STATE.update(
+            group=group, backend=chosen, folded=bool(shared), devices=every,
+            note=note)
     return rank, world, device
+
+
+def shutdown():
+    """Destroy the process groups (data plane first)."""
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    _STATE.update(group=None, backend=None, folded=False, devices=None,
+                  note=None)
 
 
 def _host_staged(tensor):
     """gloo moves host memory: device tensors go through a host copy."""
-    return (
-        dist.is_initialized() and dist.get_backend() == 'gloo' and
-        tensor.is_cuda)
+    return dist.is_initialized() and backend() == 'gloo' and tensor.is_cuda
 
 
 def shard_bounds(total, rank, world):
@@ -81,10 +197,10 @@ def broadcast_model(model, src=0):
         flat = torch.cat([t.detach().reshape(-1) for t in group])
         if _host_staged(flat):
             host = flat.cpu()
-            dist.broadcast(host, src=src)
+            dist.broadcast(host, src=src, group=data_group())
             flat = host.to(flat.device)
         else:
-            dist.broadcast(flat, src=src)
+            dist.broadcast(flat, src=src, group=data_group())
         offset = 0
         with torch.no_grad():
             for tensor in group:
@@ -144,10 +260,11 @@ def all_gather_into(local, world=None, out=None, async_op=False):
             dtype=local.dtype, device=local.device)
     if _host_staged(local):
         host = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(host, local.cpu())
+        dist.all_gather_into_tensor(host, local.cpu(), group=data_group())
         out.copy_(host)
         return (None, out) if async_op else out
-    work = dist.all_gather_into_tensor(out, local, async_op=async_op)
+    work = dist.all_gather_into_tensor(
+        out, local, group=data_group(), async_op=async_op)
     return (work, out) if async_op else out
 
 
@@ -162,7 +279,7 @@ class GatherPipeline:
 
     def __init__(self, world, shard_shape, device, dtype=torch.float32):
         self.world = world
-        self.overlap = dist.is_initialized() and dist.get_backend() == 'nccl'
+        self.overlap = dist.is_initialized() and backend() == 'nccl'
         self.buffers = [
             torch.empty(
                 (world * shard_shape[0],) + tuple(shard_shape[1:]),

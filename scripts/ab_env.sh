@@ -6,7 +6,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for round in 1 2 3; do
   for v in "$@"; do
-    env $v python $ROOT/bench.py --steps 6 --warmup 2 --sustain 0 --no-cpu-baseline --no-traffic 2>/dev/null | AB_FILTER=$AB_FILTER python -c "
+    env $v python $ROOT/bench.py --steps 6 --warmup 2 --sustain 0 --no-cpu-baseline --no-traffic --no-secondary 2>/dev/null | AB_FILTER=$AB_FILTER python -c "
 import json,sys,os; r=json.loads(sys.stdin.read()); k=r['kernels']; f=os.environ.get('AB_FILTER','')
 print('[$v] round $round: %.2f ms | ' % r['ms_per_step'] + ' '.join('%s %.3f' % (n.replace('block_','b').replace('pair_','p'), v['ms_per_step']) for n, v in sorted(k.items()) if (f in n if f else v['ms_per_step'] > 0.6)))"
   done

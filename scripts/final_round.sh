@@ -13,6 +13,6 @@ mkdir -p gpurun_out/$TAG/preprocess
 python scripts/bench_preprocess.py 2>/dev/null | tail -1 > gpurun_out/$TAG/preprocess/bench_preprocess.json
 export TMPDIR=/tmp
 (cd /tmp && timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d $ROOT/gpurun_out/$TAG/preprocess/stats -o stats -- python $ROOT/scripts/bench_preprocess.py > $ROOT/gpurun_out/$TAG/preprocess/stats.log 2>&1)
-(cd /tmp && timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d $ROOT/gpurun_out/$TAG/fargan_stats -o stats -- python $ROOT/bench.py --model fargan --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --sustain 0 > $ROOT/gpurun_out/$TAG/fargan_stats.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d $ROOT/gpurun_out/$TAG/fargan_stats -o stats -- python $ROOT/bench.py --model fargan --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --no-secondary --sustain 0 > $ROOT/gpurun_out/$TAG/fargan_stats.log 2>&1)
 find gpurun_out/$TAG -name "*.csv" -size +2M -delete
 find gpurun_out/$TAG -name "*kernel_stats.csv" | head

@@ -14,9 +14,9 @@ if [[ $WHAT == all || $WHAT == tests ]]; then
 fi
 if [[ $WHAT == all || $WHAT == bench ]]; then
   timeout 600 python bench.py > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err; echo "bench bf16 (default) rc $?"
-  timeout 600 python bench.py --gpus 2 --no-cpu-baseline --no-traffic > $OUT/bench_bf16_2ranks.json 2> $OUT/bench_bf16_2ranks.err; echo "bench 2 ranks rc $?"
-  timeout 600 python bench.py --dtype f16 --no-cpu-baseline --no-traffic > $OUT/bench_f16.json 2> $OUT/bench_f16.err; echo "bench f16 rc $?"
-  timeout 600 python bench.py --dtype fp32 --batch 8 --seconds 5 --no-cpu-baseline --no-traffic > $OUT/bench_fp32_config2.json 2> $OUT/bench_fp32.err; echo "bench fp32 rc $?"
+  timeout 600 python bench.py --gpus 2 --no-cpu-baseline --no-traffic --no-secondary > $OUT/bench_bf16_2ranks.json 2> $OUT/bench_bf16_2ranks.err; echo "bench 2 ranks rc $?"
+  timeout 600 python bench.py --dtype f16 --no-cpu-baseline --no-traffic --no-secondary > $OUT/bench_f16.json 2> $OUT/bench_f16.err; echo "bench f16 rc $?"
+  timeout 600 python bench.py --dtype fp32 --batch 8 --seconds 5 --no-cpu-baseline --no-traffic --no-secondary > $OUT/bench_fp32_config2.json 2> $OUT/bench_fp32.err; echo "bench fp32 rc $?"
   timeout 600 python bench.py --model fargan --dtype fp32 --steps 5 --warmup 1 > $OUT/bench_fargan.json 2> $OUT/bench_fargan.err; echo "bench fargan rc $?"
   for f in $OUT/bench_*.json; do python - "$f" <<'PY'
 import json, sys

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 rocm-smi --showpower --showclocks --showmaxpower --showperflevel > $OUT.static 2>&1
 ( while true; do rocm-smi --showpower --showclocks --json 2>/dev/null | tr -d '\n'; echo; sleep 0.25; done ) > $OUT.samples &
 SAMPLER=$!
-python $ROOT/bench.py --steps 400 --warmup 20 --sustain 0 --no-cpu-baseline --no-traffic "$@" > $OUT.bench.json 2>/dev/null
+python $ROOT/bench.py --steps 400 --warmup 20 --sustain 0 --no-cpu-baseline --no-traffic --no-secondary "$@" > $OUT.bench.json 2>/dev/null
 kill $SAMPLER
 python - "$OUT" <<'PY'
 import json, re, sys

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-traffic --sustain 0 $*"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-traffic --no-secondary --sustain 0 $*"
 timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH --steps 20 --warmup 2 > $OUT/stats.log 2>&1
 timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS \
     --kernel-trace -d $OUT/pmc_sq -o sq -- $BENCH --steps 1 --warmup 0 > $OUT/pmc_sq.log 2>&1

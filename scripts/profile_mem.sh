@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-traffic --sustain 0 --steps 1 --warmup 0"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-traffic --no-secondary --sustain 0 --steps 1 --warmup 0"
 run() {  # run <name> <counters...>: one PMC pass, bounded (a bad counter set aborts and can hang)
     local name=$1; shift
     timeout 150 rocprofv3 --output-format csv --pmc "$@" --kernel-trace -d $OUT/pmc_$name -o $name -- $BENCH > $OUT/pmc_$name.log 2>&1 || echo "pass $name failed"

@@ -15,7 +15,7 @@ timeout 900 python -m pytest tests/test_gpu_model.py -x -q -k "files_to_files or
 tail -3 $OUT/pytest_files.log
 for round in 1 2 3; do
   for v in "" _nox3f32; do
-    PROMONET_HIP_LIB=$ROOT/promonet_amd/lib/libpromonet_hip$v.so timeout 300 python bench.py --dtype fp32 --batch 8 --seconds 5 --steps 6 --warmup 2 --sustain 0 --no-cpu-baseline --no-traffic 2>/dev/null | python -c "
+    PROMONET_HIP_LIB=$ROOT/promonet_amd/lib/libpromonet_hip$v.so timeout 300 python bench.py --dtype fp32 --batch 8 --seconds 5 --steps 6 --warmup 2 --sustain 0 --no-cpu-baseline --no-traffic --no-secondary 2>/dev/null | python -c "
 import json,sys; r=json.loads(sys.stdin.read()); k=r['kernels']
 print('fp32 config2 variant[$v] round $round: %.2f ms | ' % r['ms_per_step'] + ' '.join('%s %.3f' % (n, v['ms_per_step']) for n, v in sorted(k.items()) if 'c32' in n or 'c64' in n))" | tee -a $OUT/ab_x3skew_f32.txt
   done

@@ -40,7 +40,8 @@ def worker(rank, world, port, totals, results):
 
     got_rank, got_world, device = distributed.init()
     assert (got_rank, got_world) == (rank, world)
-    assert device.type == 'cuda' and dist.get_backend() == 'gloo'
+    assert device.type == 'cuda' and distributed.backend() == 'gloo'
+    assert distributed.folded() and len(distributed.rank_devices()) == world
 
     # different weights per rank, engines already built (a warm-up forward)
     # BEFORE the broadcast: non-source ranks must not keep stale packed weights
@@ -183,7 +184,8 @@ def config4_worker(rank, world, port, backend, results):
     from promonet_amd import distributed
 
     _, _, device = distributed.init(backend=backend, force=True)
-    assert dist.get_backend() == backend
+    assert distributed.backend() == backend
+    assert distributed.folded() == (world > 1)
     batch, frames = 32, 861
     promonet_amd.configure(COMPUTE_DTYPE='bf16')
     torch.manual_seed(rank)                  # broadcast makes them equal

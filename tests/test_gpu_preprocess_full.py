@@ -27,6 +27,8 @@ pytestmark = pytest.mark.gpu
 FULL = (32, 861 * 256)
 RAGGED = (3, 4811 * 256 + 77)
 SHAPES = {'full': FULL, 'ragged': RAGGED}
+# per-bin loudness: conditioning-term factor of the gate (see the test)
+KAPPA = .2      # measured .055 (full) / .049 (ragged): profiles/r05/NOTES.md
 
 
 def geometry(transform, batch, samples):
@@ -157,6 +159,17 @@ def test_loudness_persistent_walk(device, cases, frames_per_group, shape):
     batch, samples = SHAPES[shape]
     case = cases[shape]
     audio = case['audio'].to(device)
+    # Per-bin dB (bands None) of a WEAK bin is ill-conditioned in fp32: an FFT
+    # carries an absolute error ~ eps x the frame's energy into every bin, so a
+    # bin 60 dB under its frame moves by 8.686 x 1e3 eps dB - on the oracle's
+    # side (numpy's float32 pocketfft: 5.8e-4 dB against its own float64 run
+    # on this input) as on ours. Over 14 M bins the tail shows (the 6 500-bin
+    # tests stay inside the plain gate). The gate for that case therefore adds
+    # the conditioning term KAPPA x eps32 x (frame amplitude / bin amplitude)
+    # x 8.686 dB; band means (what the model consumes) keep the plain gate.
+    power = (case['spec'].double() ** 2 - 1e-6).clamp_min(1e-20)
+    conditioning = (power.sum(1, keepdim=True) / power).sqrt()
+    eps32 = 2. ** -23
     for bands, second in ((8, 5), (1, 3), (None, 3), (4, 3)):
         assert_persistent(2, batch, samples)
         total, grid = assert_persistent(second, batch, samples)
@@ -164,17 +177,29 @@ def test_loudness_persistent_walk(device, cases, frames_per_group, shape):
             oracle.band_average(case['loud'], bands)
         got = promonet_amd.preprocess.loudness.from_audio(audio, bands)
         assert got.shape == want.shape
-        diff = (got.cpu() - want).abs()
-        ratio = (diff / (1e-4 + 1e-5 * want.abs())).max().item()
+        diff = (got.cpu() - want).abs().double()
+        gate = 1e-4 + 1e-5 * want.abs().double()
+        if bands is None:
+            # how many eps x conditioning the excess over the plain gate is
+            kappa = ((diff - gate).clamp_min(0.) /
+                     (8.686 * eps32 * conditioning)).max().item()
+            outside = (diff > gate).sum().item()
+            print(f'loudness {shape} per bin: {outside} of {diff.numel()} bins '
+                  f'outside the plain gate, conditioning factor {kappa:.3f}')
+            check(kappa, KAPPA, f'loudness_walk_per_bin_kappa:{shape}')
+            assert outside < 2e-5 * diff.numel()
+            gate = gate + 8.686 * KAPPA * eps32 * conditioning
+        ratio = (diff / gate).max().item()
         print(f'loudness {shape} bands {bands} fpg {frames_per_group}: {total} '
               f'groups on {grid} workgroups, max-abs {diff.max():.3e} dB, '
               f'worst / gate {ratio:.3f}')
         check(ratio, 1., f'loudness_walk_gate_ratio:{shape}:{bands}')
         again = promonet_amd.preprocess.loudness.from_audio(audio, bands)
         assert torch.equal(got, again)
-    # (the utterances' levels - hence their max - 80 dB floors - span 30 dB)
+    # (the utterances' levels - hence their max - 80 dB floors - differ: 5 dB
+    # steps, 7 levels in the full batch, 3 in the ragged one)
     level = 20. * torch.log10(case['audio'].abs().amax(dim=1))
-    assert level.max() - level.min() > 25.
+    assert level.max() - level.min() > (25. if batch > 7 else 8.)
 
 
 def test_walk_equals_one_group_per_workgroup(device, cases):
