@@ -256,10 +256,68 @@ class Generator(torch.nn.Module):
             along_time(spectral_balance_ratios), along_time(loudness_ratios)),
             dim=1)
 
-    def packed_inference(self, x):
-        """(B, 53, frames) -> (B, 1, 256 frames) float32 (:313-343)"""
+    def packed_inference(self, x, graph=False):
+        """(B, 53, frames) -> (B, 1, 256 frames) float32 (:313-343).
+
+        `graph=True` is the low-latency schedule for the streaming (nn~) use
+        of this method - one small chunk per call, where the ~40 kernel
+        launches of a forward cost more than the kernels: the whole call
+        (unpack, feature preparation, vocoder) is captured ONCE per input
+        shape as a hipGraph and replayed on every later call - one launch
+        instead of forty, bit-identical output
+        (tests/test_gpu_model.py::test_packed_inference_graph). HiFi-GAN only."""
+        if graph:
+            return self._packed_graph(x)
         unpacked = [t.contiguous() for t in self.unpack_features(x)]
         return self(*unpacked, self.default_previous_samples).to(torch.float)
+
+    # captured graphs kept per Generator, oldest dropped first
+    MAX_PACKED_GRAPHS = 8
+
+    def _packed_graph(self, x):
+        if not isinstance(self.model, HiFiGAN):
+            raise ValueError(
+                'packed_inference(graph=True) is implemented for the HiFi-GAN '
+                'vocoder (FARGAN checks its inter-workgroup exchanges on the '
+                'host after every forward)')
+        _lib.require_gpu(x)
+        x = x.to(torch.float32)
+        self.model.engine()                    # (re)built outside any capture
+        key = (tuple(x.shape), x.device, self.model._generation)
+        cache = self.__dict__.setdefault('_packed_graphs', {})
+        entry = cache.get(key)
+        if entry is None:
+            for stale in [k for k in cache if k[2] != key[2]]:
+                del cache[stale]
+            while len(cache) >= self.MAX_PACKED_GRAPHS:
+                del cache[next(iter(cache))]
+            entry = cache[key] = self._capture_packed(x)
+        entry['input'].copy_(x)
+        entry['graph'].replay()
+        return entry['output'].clone()
+
+    def _capture_packed(self, x):
+        """One eager call (engine packed, host-side constants cached), then the
+        capture. The graph gets a workspace of its OWN: the module's shared
+        one may be re-allocated by a later, larger forward, and a captured
+        kernel keeps the pointer it was recorded with."""
+        vocoder = self.model
+        with torch.no_grad(), torch.cuda.device(x.device):
+            static = x.clone()
+            self.packed_inference(static)
+            shared = vocoder._workspace
+            vocoder._workspace = None
+            try:
+                graph = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize(x.device)
+                with torch.cuda.graph(graph):
+                    output = self.packed_inference(static)
+                private = vocoder._workspace
+            finally:
+                vocoder._workspace = shared
+            torch.cuda.synchronize(x.device)
+        return {'graph': graph, 'input': static, 'output': output,
+                'workspace': private}
 
     def remove_weight_norm(self):
         self.model.remove_weight_norm()

@@ -37,6 +37,7 @@ class HiFiGAN(torch.nn.Module):
 
         self._engine = None
         self._engine_key = None
+        self._generation = 0     # bumped whenever the engine is dropped
         self._workspace = None
         self._busy = None        # (stream, event) of the last forward
         self.register_load_state_dict_post_hook(
@@ -93,6 +94,9 @@ class HiFiGAN(torch.nn.Module):
     def _destroy(self):
         if getattr(self, '_engine', None) is not None:
             _lib.lib().pm_hifigan_destroy(self._engine)
+            # (captured graphs hold the old engine's weight pointers:
+            # Generator.packed_inference(graph=True) keys its cache on this)
+            self._generation = getattr(self, '_generation', 0) + 1
         self._engine = None
         self._engine_key = None
 

@@ -849,3 +849,59 @@ def test_packed_interface(device, golden_default, default_state):
     with torch.inference_mode():
         zeros = model.packed_inference(torch.zeros(1, 53, 32, device=device))
     assert tuple(zeros.shape) == (1, 1, 8192) and torch.isfinite(zeros).all()
+
+
+@pytest.mark.parametrize('dtype', ['checkpoint', 'bf16'])
+def test_packed_inference_graph(device, default_state, dtype):
+    """The low-latency schedule of the streaming (nn~) use, generator.py:
+    334-343,363-368: `packed_inference(x, graph=True)` replays one captured
+    hipGraph per input shape. Bit-identical to the eager call at the nn~ chunk
+    sizes, for inputs other than the captured ones; the graph owns its
+    workspace (a larger eager forward in between does not disturb it) and is
+    re-captured when the weights change."""
+    model = make_model(default_state, dtype, device)
+    gen = torch.Generator().manual_seed(77)
+
+    def packed(batch, frames):
+        inputs = oracle.synthetic_inputs(batch, frames, seed=frames + batch)
+        with torch.inference_mode():
+            return model.pack_features(
+                inputs[0].to(device), inputs[1][:, None].to(device),
+                inputs[2][:, None].to(device), *on(device, inputs[3:])).clone()
+
+    for frames in (8, 16, 32, 64):
+        first, second = packed(1, frames), packed(1, frames + 1)[..., :frames]
+        with torch.inference_mode():
+            eager = [model.packed_inference(t) for t in (first, second)]
+        replay = [model.packed_inference(t, graph=True) for t in (first, second)]
+        assert replay[0].shape == (1, 1, frames * 256)
+        for want, got in zip(eager, replay):
+            assert torch.equal(want, got), frames
+        assert not torch.equal(replay[0], replay[1])
+    assert len(model._packed_graphs) == 4
+    # under inference mode too, and a batch of 2
+    pair = packed(2, 16)
+    with torch.inference_mode():
+        assert torch.equal(
+            model.packed_inference(pair, graph=True),
+            model.packed_inference(pair))
+    # a much larger eager forward re-allocates the module's shared workspace
+    chunk = packed(1, 32)
+    before = model.packed_inference(chunk, graph=True)
+    with torch.inference_mode():
+        model.packed_inference(packed(3, 500))
+    torch.cuda.synchronize()
+    assert torch.equal(model.packed_inference(chunk, graph=True), before)
+    # new weights: the engine is rebuilt, stale graphs are dropped
+    state = {k: v.clone() for k, v in default_state.items()}
+    state['model.model.5.weight'] = state['model.model.5.weight'] * .5
+    model.load_state_dict(state)
+    with torch.inference_mode():
+        want = model.packed_inference(chunk)
+    got = model.packed_inference(chunk, graph=True)
+    assert torch.equal(want, got) and not torch.equal(got, before)
+    assert len(model._packed_graphs) == 1
+    # the reference's export-time self test shape (generator.py:363-368)
+    zeros = model.packed_inference(
+        torch.zeros(1, 53, 32, device=device), graph=True)
+    assert tuple(zeros.shape) == (1, 1, 8192) and torch.isfinite(zeros).all()
