@@ -71,39 +71,85 @@ struct FftArgs {
     int use_thr; float thr;  // EPI 4
 };
 
-__device__ __forceinline__ float2 pm_cadd(float2 a, float2 b) {
-    return make_float2(a.x + b.x, a.y + b.y);
+// Complex arithmetic on register PAIRS (re, im), one packed instruction per
+// complex operation: the swizzles and signs of a multiplication by +-i, a
+// conjugation or a complex product are operand modifiers of v_pk_add_f32 /
+// v_pk_mul_f32 / v_pk_fma_f32 (op_sel picks the half of a source that feeds
+// the low result, op_sel_hi the high one; neg_lo / neg_hi negate a source for
+// one half). hipcc does not find these forms from scalar or vector C++ - it
+// re-pairs registers with v_mov / v_pk_mov around every rotation (round 4's
+// build: 102 moves and 275 arithmetic instructions a frame; this one: 182
+// arithmetic, 0 moves) - so they are spelled out. Plain (non-volatile) asm:
+// the compiler still schedules, CSEs and allocates around them.
+typedef float pm_v2 __attribute__((ext_vector_type(2)));
+#define PM_PK2(name, mods)                                                    \
+    __device__ __forceinline__ pm_v2 name(pm_v2 a, pm_v2 b) {                 \
+        pm_v2 d;                                                              \
+        asm("v_pk_add_f32 %0, %1, %2" mods : "=v"(d) : "v"(a), "v"(b));       \
+        return d;                                                             \
+    }
+PM_PK2(pk_add, "")                                                 // a + b
+PM_PK2(pk_sub, " neg_lo:[0,1] neg_hi:[0,1]")                       // a - b
+PM_PK2(pk_add_i, " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")     // a + i b
+PM_PK2(pk_sub_i, " op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")     // a - i b
+PM_PK2(pk_add_conj, " neg_hi:[0,1]")                               // a + conj b
+PM_PK2(pk_sub_conj, " neg_lo:[0,1]")                               // a - conj b
+#undef PM_PK2
+// a w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x)
+__device__ __forceinline__ pm_v2 pk_cmul(pm_v2 a, pm_v2 w) {
+    pm_v2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] "
+        "neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    return d;
 }
-__device__ __forceinline__ float2 pm_csub(float2 a, float2 b) {
-    return make_float2(a.x - b.x, a.y - b.y);
+// z[i] *= w[i] for i = FIRST .. N - 1: every product's first half, then every
+// second half - a packed instruction that consumes the result of the one in
+// front of it costs a wait state (an s_nop in the instruction stream)
+template <int FIRST, int N>
+__device__ __forceinline__ void pk_cmul_each(pm_v2 (&z)[N], const pm_v2 (&w)[N]) {
+    pm_v2 t[N];
+#pragma unroll
+    for (int i = FIRST; i < N; ++i)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]"
+            : "=v"(t[i]) : "v"(z[i]), "v"(w[i]));
+#pragma unroll
+    for (int i = FIRST; i < N; ++i)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] "
+            "neg_lo:[0,1,0]" : "=v"(z[i]) : "v"(z[i]), "v"(w[i]), "v"(t[i]));
 }
-__device__ __forceinline__ float2 pm_cmul(float2 a, float2 w) {
-    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+// |a|^2
+__device__ __forceinline__ float pk_norm(pm_v2 a) {
+    const pm_v2 q = a * a;
+    return q.x + q.y;
 }
 
-// 4-point DFT (W4 = -i): o[r] = sum_n c[n] (-i)^(n r)
-__device__ __forceinline__ void pm_dft4(
-    float2 c0, float2 c1, float2 c2, float2 c3, float2& o0, float2& o1,
-    float2& o2, float2& o3) {
-    const float2 d0 = pm_cadd(c0, c2), d1 = pm_csub(c0, c2);
-    const float2 d2 = pm_cadd(c1, c3), e = pm_csub(c1, c3);
-    const float2 d3 = make_float2(e.y, -e.x);       // -i (c1 - c3)
-    o0 = pm_cadd(d0, d2); o1 = pm_cadd(d1, d3);
-    o2 = pm_csub(d0, d2); o3 = pm_csub(d1, d3);
-}
-
-// In-place 8-point DFT, a[k] <- sum_n a[n] W8^(n k), W8 = exp(-2 pi i / 8)
-__device__ __forceinline__ void pm_radix8(float2 (&a)[8]) {
+// In-place 8-point DFT, a[k] <- sum_n a[n] W8^(n k), W8 = exp(-2 pi i / 8):
+// 28 packed instructions (the two 4-point halves with their +-i rotations
+// folded into the additions, W8 and W8^3 as one scaling of a sum and a
+// difference)
+__device__ __forceinline__ void pm_radix8(pm_v2 (&a)[8]) {
     const float h = 0.70710678118654752440f;
-    const float2 b0 = pm_cadd(a[0], a[4]), b4 = pm_csub(a[0], a[4]);
-    const float2 b1 = pm_cadd(a[1], a[5]), e5 = pm_csub(a[1], a[5]);
-    const float2 b2 = pm_cadd(a[2], a[6]), e6 = pm_csub(a[2], a[6]);
-    const float2 b3 = pm_cadd(a[3], a[7]), e7 = pm_csub(a[3], a[7]);
-    const float2 b5 = make_float2((e5.x + e5.y) * h, (e5.y - e5.x) * h);
-    const float2 b6 = make_float2(e6.y, -e6.x);
-    const float2 b7 = make_float2((e7.y - e7.x) * h, -(e7.x + e7.y) * h);
-    pm_dft4(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
-    pm_dft4(b4, b5, b6, b7, a[1], a[3], a[5], a[7]);
+    const pm_v2 b0 = pk_add(a[0], a[4]), b4 = pk_sub(a[0], a[4]);
+    const pm_v2 b1 = pk_add(a[1], a[5]), e5 = pk_sub(a[1], a[5]);
+    const pm_v2 b2 = pk_add(a[2], a[6]), e6 = pk_sub(a[2], a[6]);
+    const pm_v2 b3 = pk_add(a[3], a[7]), e7 = pk_sub(a[3], a[7]);
+    // even outputs: the 4-point DFT of b0 .. b3
+    {
+        const pm_v2 d0 = pk_add(b0, b2), d1 = pk_sub(b0, b2);
+        const pm_v2 d2 = pk_add(b1, b3), e = pk_sub(b1, b3);
+        a[0] = pk_add(d0, d2); a[2] = pk_sub_i(d1, e);
+        a[4] = pk_sub(d0, d2); a[6] = pk_add_i(d1, e);
+    }
+    // odd outputs: the 4-point DFT of b4, W8 e5, -i e6, W8^3 e7 with
+    // W8 e5 = h (e5 - i e5), W8^3 e7 = -h (e7 + i e7)
+    {
+        const pm_v2 u5 = pk_sub_i(e5, e5), u7 = pk_add_i(e7, e7);
+        const pm_v2 d0 = pk_sub_i(b4, e6), d1 = pk_add_i(b4, e6);
+        const pm_v2 d2 = pk_sub(u5, u7) * h, e = pk_add(u5, u7) * h;
+        a[1] = pk_add(d0, d2); a[3] = pk_sub_i(d1, e);
+        a[5] = pk_sub(d0, d2); a[7] = pk_add_i(d1, e);
+    }
 }
 
 // Orders the lanes' LDS accesses of one wave: the exchanges below hand data
@@ -131,18 +177,18 @@ __host__ __device__ constexpr int pm_fft_smem_bytes() {
 // position p = 256 t + n maps to audio sample p - 384, reflected at both ends
 // (torch.nn.functional.pad(mode='reflect'), spectrogram.py:36-37).
 __device__ __forceinline__ void pm_fft_load_frame(
-    float2 (&raw)[8], const float* __restrict__ ab, int t, int N, int lane) {
+    pm_v2 (&raw)[8], const float* __restrict__ ab, int t, int N, int lane) {
     const int base = t * PM_FFT_HOP - PM_FFT_PAD;
     if (base >= 0 && base + PM_FFT_N <= N) {          // (wave-uniform)
         const float* p = ab + base + 2 * lane;
         if ((reinterpret_cast<uintptr_t>(p) & 7) == 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                raw[i] = *reinterpret_cast<const float2*>(p + 128 * i);
+                raw[i] = *reinterpret_cast<const pm_v2*>(p + 128 * i);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                raw[i] = make_float2(p[128 * i], p[128 * i + 1]);
+                raw[i] = pm_v2{p[128 * i], p[128 * i + 1]};
         }
     } else {
 #pragma unroll
@@ -155,7 +201,7 @@ __device__ __forceinline__ void pm_fft_load_frame(
                 j = j >= N ? 2 * (N - 1) - j : j;
                 v[e] = ab[j];
             }
-            raw[i] = make_float2(v[0], v[1]);
+            raw[i] = pm_v2{v[0], v[1]};
         }
     }
 }
@@ -172,7 +218,7 @@ void pm_stft_fft_kernel(FftArgs a) {
     constexpr int WS = 576;          // complex slots per wave (8 x 72)
     constexpr int OS = FR + 1;       // staging row pitch (floats)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* work = reinterpret_cast<float2*>(smem);
+    pm_v2* work = reinterpret_cast<pm_v2*>(smem);
     [[maybe_unused]] float* ost = reinterpret_cast<float*>(work + NW * WS);
     [[maybe_unused]] float* melv = ost + PM_FFT_BINS * OS;   // EPI 4
 
@@ -203,9 +249,13 @@ void pm_stft_fft_kernel(FftArgs a) {
     const int T = a.T, N = a.N;
     const float* ab = a.audio + (size_t)b * N;
 
-    // the first frame's samples are requested before anything else
-    float2 raw[8];
-    if (t0 + wave < T) pm_fft_load_frame(raw, ab, t0 + wave, N, lane);
+    // the first frame's samples are requested before anything else. Every
+    // frame load of this kernel is UNCONDITIONAL (a frame index past the end
+    // of the utterance is clamped to its last frame: computed, never stored) -
+    // conditional reloads of a loop-carried register array cost a copy of it
+    // in and out of every branch (24 v_mov_b64 a frame, round 4's build)
+    pm_v2 raw[8];
+    pm_fft_load_frame(raw, ab, min(t0 + wave, T - 1), N, lane);
 
     [[maybe_unused]] bool mel_in_lds = false;
     if constexpr (EPI == 4) {
@@ -217,27 +267,50 @@ void pm_stft_fft_kernel(FftArgs a) {
 
     // ---- per-lane constants -------------------------------------------------
     const float* __restrict__ tab = a.tables;
-    const float2* __restrict__ w512 =
-        reinterpret_cast<const float2*>(tab + PM_FFT_TAB_W512);
-    const float2* __restrict__ w1024 =
-        reinterpret_cast<const float2*>(tab + PM_FFT_TAB_W1024);
+    const pm_v2* __restrict__ w512 =
+        reinterpret_cast<const pm_v2*>(tab + PM_FFT_TAB_W512);
+    const pm_v2* __restrict__ w1024 =
+        reinterpret_cast<const pm_v2*>(tab + PM_FFT_TAB_W1024);
     const int k0p = lane >> 3, m0p = lane & 7;
-    // (the unpacking twiddles W1024^k, k = lane + 64 j, are read where they
-    // are used - 4 KB that stay in L1, coalesced - instead of holding 16 more
-    // registers across the frame loop)
-    float2 win[8], twa[8], twb[8];
+    pm_v2 win[8], twa[8], twb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        win[i] = *reinterpret_cast<const float2*>(tab + 2 * (64 * i + lane));
+        win[i] = *reinterpret_cast<const pm_v2*>(tab + 2 * (64 * i + lane));
         twa[i] = w512[lane * i];            // W512^(m k0), m = lane
         twb[i] = w512[8 * m0p * i];         // W64^(m0 q0)
+    }
+    // Unpacking: bins k = lane + 64 j (j < 4) and 512 - k come out of the SAME
+    // pair (Z[k], Z[512 - k]) - a lane takes both, so a frame reads 8 values
+    // and 4 twiddles (kept here, as -i W1024^k) instead of 16 and 8
+    pm_v2 wun[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const pm_v2 w = w1024[lane + 64 * j];
+        wun[j] = pm_v2{w.y, -w.x};         // -i w
+    }
+    // EPI 3 / 5: the A-weights of this lane's 8 (+ 1) bins
+    [[maybe_unused]] float wlo[4], whi[4], w256 = 0.f;
+    if constexpr (EPI == 3 || EPI == 5) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wlo[j] = a.weights[lane + 64 * j];
+            whi[j] = a.weights[512 - lane - 64 * j];
+        }
+        w256 = a.weights[256];
     }
     [[maybe_unused]] float floor_db = 0.f;
     [[maybe_unused]] int floor_of = -1;    // utterance floor_db belongs to
     [[maybe_unused]] int parity = 0;       // EPI 2: reduction slots alternate
-    float2* wk = work + wave * WS;
+    pm_v2* wk = work + wave * WS;
 #pragma unroll 1
     for (;;) {
+    // the group after this one (its first frame is requested under the last
+    // frame's transform)
+    const int gn = g + stride;
+    const bool more = gn < end;             // (workgroup-uniform)
+    const int bn = more ? gn / a.groups : b;
+    const int t0n = more ? (gn - bn * a.groups) * FR : t0;
+    const float* __restrict__ abn = a.audio + (size_t)bn * N;
     float local_max = EPI == 2 ? 0.f : -INFINITY;   // (EPI 2: of |X|^2 >= 0)
     if constexpr (EPI == 3 || EPI == 5) {
         if (floor_of != b) {               // (workgroup-uniform)
@@ -263,21 +336,25 @@ void pm_stft_fft_kernel(FftArgs a) {
 #pragma unroll 1
     for (int i = 0; i < FPW; ++i) {
         const int fl = wave + NW * i;       // frame of this workgroup
-        if (t0 + fl >= T) break;            // (wave-uniform)
-        float2 z[8];
+        // (frames past the utterance's end are transforms of its last frame:
+        // their columns of the staging tile are never written out)
+        [[maybe_unused]] const bool valid = t0 + fl < T;   // (wave-uniform)
+        pm_v2 z[8];
         // stage A: lane m holds z[64 n2 + m], n2 = 0..7
 #pragma unroll
-        for (int n2 = 0; n2 < 8; ++n2)
-            z[n2] = make_float2(raw[n2].x * win[n2].x, raw[n2].y * win[n2].y);
-        // (the next frame's samples fly under this frame's transform)
-        if (i + 1 < FPW && t0 + fl + NW < T) {
+        for (int n2 = 0; n2 < 8; ++n2) z[n2] = raw[n2] * win[n2];
+        // (the next frame's samples fly under this frame's transform: the
+        // wave's next frame of this group, or the first one of the next group)
+        {
+            const bool same = i + 1 < FPW;
+            const float* __restrict__ an = same ? ab : abn;
+            const int tn = same ? t0 + fl + NW : t0n + wave;
             int glane = lane;              // (opaque per frame, see `wlane`)
             asm volatile("" : "+v"(glane));
-            pm_fft_load_frame(raw, ab, t0 + fl + NW, N, glane);
+            pm_fft_load_frame(raw, an, min(tn, T - 1), N, glane);
         }
         pm_radix8(z);
-#pragma unroll
-        for (int k0 = 1; k0 < 8; ++k0) z[k0] = pm_cmul(z[k0], twa[k0]);
+        pk_cmul_each<1>(z, twa);
         pm_wave_lds_sync();                 // (previous frame's reads of wk)
 #pragma unroll
         for (int k0 = 0; k0 < 8; ++k0) wk[k0 * 72 + lane] = z[k0];
@@ -286,8 +363,7 @@ void pm_stft_fft_kernel(FftArgs a) {
 #pragma unroll
         for (int m1 = 0; m1 < 8; ++m1) z[m1] = wk[k0p * 72 + 8 * m1 + m0p];
         pm_radix8(z);
-#pragma unroll
-        for (int q0 = 1; q0 < 8; ++q0) z[q0] = pm_cmul(z[q0], twb[q0]);
+        pk_cmul_each<1>(z, twb);
         pm_wave_lds_sync();
 #pragma unroll
         for (int q0 = 0; q0 < 8; ++q0) wk[k0p * 72 + q0 * 9 + m0p] = z[q0];
@@ -301,46 +377,68 @@ void pm_stft_fft_kernel(FftArgs a) {
 #pragma unroll
         for (int q1 = 0; q1 < 8; ++q1) wk[k0p + 8 * m0p + 64 * q1] = z[q1];
         pm_wave_lds_sync();
-        // unpack: X[k] = (Z[k] + conj Z[512 - k]) / 2
-        //                + W1024^k (Z[k] - conj Z[512 - k]) / (2 i)
-        int ul = lane;          // (opaque: the twiddle loads stay in the loop)
-        asm volatile("" : "+v"(ul));
+        // unpack: with E2 = Z[k] + conj Z[512 - k], D = Z[k] - conj Z[512 - k]
+        //   2 X[k] = E2 - i W1024^k D,   2 conj X[512 - k] = E2 + i W1024^k D
+        // (k = 0 pairs with itself: X[0] and X[512] = Re Z[0] +- Im Z[0])
         [[maybe_unused]] float bs[8];       // EPI 5: this lane's bin of band j
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = lane + 64 * j;
-            const float2 zk = wk[k];
-            const float2 zm = wk[(512 - k) & 511];
-            const float ex = 0.5f * (zk.x + zm.x), ey = 0.5f * (zk.y - zm.y);
-            const float dx = 0.5f * (zk.x - zm.x), dy = 0.5f * (zk.y + zm.y);
-            const float2 xo = make_float2(dy, -dx);
-            const float2 wx = pm_cmul(xo, w1024[ul + 64 * j]);
-            const float re = ex + wx.x, im = ey + wx.y;
-            const float pw = re * re + im * im;
+        auto bin_out = [&](float pw4, int k, [[maybe_unused]] float weight,
+                           [[maybe_unused]] int band) {
+            // pw4 = 4 |X[k]|^2
             if constexpr (EPI == 1 || EPI == 4) {
-                ost[k * OS + fl] = PM_FFT_SQRT(pw + 1e-6f);
+                ost[k * OS + fl] = PM_FFT_SQRT(fmaf(pw4, 0.25f, 1e-6f));
             } else if constexpr (EPI == 2) {
                 // (the dB map is monotonic: the maximum is taken over |X|^2
                 // and mapped once per group)
-                local_max = fmaxf(local_max, pw);
+                local_max = fmaxf(local_max, valid ? pw4 : 0.f);
             } else {
-                const float v = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, pw));
-                {
-                    float u = fmaxf(v, floor_db) + a.weights[k];
-                    u = u < a.min_db ? a.min_db : u;
-                    if constexpr (EPI == 5) bs[j] = u;
-                    else ost[k * OS + fl] = u;
+                const float v = PM_DB_PER_LOG2 *
+                                __log2f(fmaxf(1e-10f, 0.25f * pw4));
+                float u = fmaxf(v, floor_db) + weight;
+                u = u < a.min_db ? a.min_db : u;
+                if constexpr (EPI == 5) bs[band] = u;
+                else ost[k * OS + fl] = u;
+            }
+        };
+        {
+            pm_v2 e2[4], dd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + 64 * j;
+                const pm_v2 zk = wk[k];
+                const pm_v2 zm = wk[(512 - k) & 511];
+                e2[j] = pk_add_conj(zk, zm);
+                dd[j] = pk_sub_conj(zk, zm);
+            }
+            pk_cmul_each<0>(dd, wun);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lane + 64 * j;
+                bin_out(pk_norm(pk_add(e2[j], dd[j])), k,
+                        (EPI == 3 || EPI == 5) ? wlo[j] : 0.f, j);
+                bin_out(pk_norm(pk_sub(e2[j], dd[j])), 512 - k,
+                        (EPI == 3 || EPI == 5) ? whi[j] : 0.f, 7 - j);
+            }
+        }
+        {
+            // bin 256 pairs with itself: |X[256]| = |Z[256]|; lane 0 takes it
+            const float pw4 = 4.f * pk_norm(wk[256]);
+            if constexpr (EPI == 5) {
+                // lane 0's partner bins 448, 384, 320 sit one band above where
+                // the other lanes' do (512 - 64 j = 64 (8 - j)): shift them up
+                // and put bin 256 into band 4
+                const float v = PM_DB_PER_LOG2 *
+                                __log2f(fmaxf(1e-10f, 0.25f * pw4));
+                float u = fmaxf(v, floor_db) + w256;
+                u = u < a.min_db ? a.min_db : u;
+                if (lane == 0) {
+                    bs[7] += bs[6]; bs[6] = bs[5]; bs[5] = bs[4]; bs[4] = u;
+                    bs[4] += 0.f;
                 }
+            } else if (lane == 0) {
+                bin_out(pw4, 256, w256, 4);
             }
         }
         if constexpr (EPI == 5) {
-            // bin 512 (Re Z[0] - Im Z[0]) closes band 7: lane 0 adds it
-            const float2 z0 = wk[0];
-            const float re0 = z0.x - z0.y;
-            const float v0 = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, re0 * re0));
-            float u0 = fmaxf(v0, floor_db) + a.weights[512];
-            u0 = u0 < a.min_db ? a.min_db : u0;
-            if (lane == 0) bs[7] += u0;
             // 8 sums over 64 lanes in 10 exchanges: three halving steps (a
             // lane keeps the bands of its own half and adds the partner's
             // values for them), then three plain ones; lane 8 band ends up
@@ -377,40 +475,14 @@ void pm_stft_fft_kernel(FftArgs a) {
                 const int band = lane >> 3;
                 ost[band * OS + fl] = v1 / (band == 7 ? 65.f : 64.f);
             }
-        } else
-        if (lane == 0) {                    // bin 512: Re Z[0] - Im Z[0]
-            const float2 z0 = wk[0];
-            const float re = z0.x - z0.y;
-            const float pw = re * re;
-            if constexpr (EPI == 1 || EPI == 4) {
-                ost[512 * OS + fl] = PM_FFT_SQRT(pw + 1e-6f);
-            } else if constexpr (EPI == 2) {
-                local_max = fmaxf(local_max, pw);
-            } else {
-                const float v = PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, pw));
-                {
-                    float u = fmaxf(v, floor_db) + a.weights[512];
-                    u = u < a.min_db ? a.min_db : u;
-                    ost[512 * OS + fl] = u;
-                }
-            }
         }
     }
 
-    // the next group of this workgroup; its first frame's samples fly under
-    // the write-out of this one
-    const int gn = g + stride;
-    const bool more = gn < end;             // (workgroup-uniform)
-    const int bn = more ? gn / a.groups : b;
-    const int t0n = more ? (gn - bn * a.groups) * FR : t0;
-    const float* __restrict__ abn = a.audio + (size_t)bn * N;
-    // (opaque copies of the thread / lane index: the write-out's and this
-    // load's per-lane addresses are recomputed per group instead of being kept
-    // in registers across the frame loop, which sits at the 128-register bound
-    // of four waves per SIMD)
-    int wtid = tid, wlane = lane;
-    asm volatile("" : "+v"(wtid), "+v"(wlane));
-    if (more && t0n + wave < T) pm_fft_load_frame(raw, abn, t0n + wave, N, wlane);
+    // (opaque copy of the thread index: the write-out's per-lane addresses are
+    // recomputed per group instead of being kept in registers across the
+    // frame loop, which sits at the 128-register bound of four waves per SIMD)
+    int wtid = tid;
+    asm volatile("" : "+v"(wtid));
 
     if constexpr (EPI == 2) {
         // one plain store per group (atomics on 32 addresses serialise); the
@@ -429,16 +501,32 @@ void pm_stft_fft_kernel(FftArgs a) {
 #pragma unroll
             for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
             a.group_max[(size_t)b * a.groups + t0 / FR] =
-                PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, m));
+                PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, 0.25f * m));   // (m = 4 |X|^2)
         }
     } else {
     __syncthreads();
     const int nf = min(FR, T - t0);         // frames this group owns
     if (EPI == 1 || (EPI == 3 && a.rows == PM_FFT_BINS)) {
+        // a thread takes FOUR consecutive frames of one bin: one 16-byte store
+        // (rows of the (.., T) output are only 4-byte aligned - T is odd -
+        // which global_store_dwordx4 accepts) instead of four stores with
+        // their index arithmetic: 4 (8 at 32 frames) passes over the tile
+        // instead of 16 - the write-out was 80 of a frame's 440 instructions
         float* ob = a.out + (size_t)b * PM_FFT_BINS * T + t0;
-        for (int idx = wtid; idx < PM_FFT_BINS * FR; idx += NT) {
-            const int bin = idx / FR, c = idx % FR;
-            if (c < nf) ob[(size_t)bin * T + c] = ost[bin * OS + c];
+        constexpr int QR = FR / 4;                  // quads per row
+        typedef float pm_f4u __attribute__((ext_vector_type(4), aligned(4)));
+        for (int idx = wtid; idx < PM_FFT_BINS * QR; idx += NT) {
+            const int bin = idx / QR, c = (idx % QR) * 4;
+            const float* src = ost + bin * OS + c;
+            float* dst = ob + (size_t)bin * T + c;
+            if (c + 3 < nf) {
+                const pm_f4u v = {src[0], src[1], src[2], src[3]};
+                *reinterpret_cast<pm_f4u*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    if (c + e < nf) dst[e] = src[e];
+            }
         }
     } else if constexpr (EPI == 5) {
         float* ob = a.out + (size_t)b * 8 * T + t0;

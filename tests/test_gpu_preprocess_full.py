@@ -3,8 +3,8 @@ BENCHMARKED: persistent FFT workgroups that walk several (utterance, frame
 group) pairs each (pm_fft.h: `g += stride`, per-XCD ranges, table and LDS reuse
 across groups, the two loudness passes indexing their per-group maxima alike).
 A workgroup only iterates when there are more groups than resident workgroups
-(occupancy x CUs: 512 for magnitude / log-mel, 768 for the loudness shapes, 256
-with 32 frames per group) - the other preprocess tests stay below that, so every
+(occupancy x CUs: 512 for magnitude / log-mel, 1024 for the loudness shapes, 256
+/ 512 with 32 frames per group) - the other preprocess tests stay below that, so every
 test here ASSERTS the geometry through pm_stft_launch_info before it compares.
 
 Reference: promonet/preprocess/spectrogram.py:15-60,111-133,
@@ -22,10 +22,11 @@ from util import check
 pytestmark = pytest.mark.gpu
 
 # BASELINE.json's workload (batch 32 x 10 s = 861 frames) and a ragged one:
-# B = 3, N % 256 != 0, 301 groups of 16 an utterance -> 903 groups in all
-# (903 % 8 = 7; 453 groups of 32, 453 % 8 = 5)
+# B = 3, N % 256 != 0, 438 groups of 16 an utterance -> 1314 groups in all
+# (1314 % 8 = 2; 657 groups of 32, 657 % 8 = 1) - more than the 1024
+# workgroups the loudness shapes keep resident since round 5
 FULL = (32, 861 * 256)
-RAGGED = (3, 4811 * 256 + 77)
+RAGGED = (3, 7003 * 256 + 77)
 SHAPES = {'full': FULL, 'ragged': RAGGED}
 # per-bin loudness: conditioning-term factor of the gate (see the test)
 KAPPA = .2      # measured .055 (full) / .049 (ragged): profiles/r05/NOTES.md
