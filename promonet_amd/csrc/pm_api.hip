@@ -1681,11 +1681,11 @@ static int fft_launch(FftArgs& a, hipStream_t s,
         if (rc) return rc;
     }
     // 16 frames by EIGHT waves of two frames for the magnitude / log-mel
-    // launches: two 512-thread workgroups per CU at 128 registers = four
-    // waves per SIMD to cover the eight wave-private LDS hand-overs of a frame
-    // (profiles/r04/stft_pmc.txt: magnitude 53.6 -> 50.4 us, log-mel 62.7 ->
-    // 50.6 us; the dB epilogues of the loudness passes want 166 registers and
-    // lose 50 % this way: they stay on four waves of four frames)
+    // launches (two 512-thread workgroups per CU: their 513 x 17 staging tiles
+    // fill the LDS), four waves of four frames for the loudness passes, which
+    // stage 8 rows or nothing and keep four workgroups per CU resident (round 5:
+    // every FFT kernel fits 128 registers; measured shapes and their history:
+    // profiles/r04/stft_pmc.txt, profiles/r05/ab_fft_packed.txt)
     if (frames_per_group == 32)
         return fft_launch_shape<EPI, 8, 4>(a, s, dry_grid);
 #ifndef PM_FFT_LOUD_8X2

@@ -9,16 +9,24 @@
 // into 512 complex points z[n] = x[2n] + i x[2n + 1], transformed by a
 // 512-point complex FFT (three radix-8 stages, 8 points per lane in registers,
 // two wave-private exchanges through LDS), and unpacked into the 513 bins of
-// the real transform. A workgroup owns FR consecutive frames of one utterance:
-// every wave loads its frame's samples straight into registers (coalesced
-// 512-byte rows, the next frame requested before the current one is
-// transformed; the 4x overlap of neighbouring frames is served by L1 / L2, the
-// reflect padding is resolved on the fly in the two edge frames), and the
-// 513 x FR results are transposed through LDS so that the (B, 513, T)
-// spectrogram is written in rows of FR consecutive frames.
+// the real transform - bins k and 512 - k out of the same pair (Z[k],
+// Z[512 - k]), so a lane reads 8 values and keeps 4 twiddles. A workgroup owns
+// FR consecutive frames of one utterance: every wave loads its frame's samples
+// straight into registers (coalesced 512-byte rows, the next frame requested
+// before the current one is transformed, unconditionally - a frame past the
+// end is a transform of the last one, never stored; the 4x overlap of
+// neighbouring frames is served by L1 / L2, the reflect padding is resolved on
+// the fly in the two edge frames), and the 513 x FR results are transposed
+// through LDS so that the (B, 513, T) spectrogram is written in rows of FR
+// consecutive frames, 16 bytes a store.
 // HBM traffic = the algorithmic 4 B / sample in + 2052 B / frame out
 // (the GEMM formulation did 40x the FLOPs: 57.9 GFLOP of dense DFT against
 // ~1.4 GFLOP of FFT at batch 32 x 10 s).
+// The kernel is INSTRUCTION-ISSUE bound (profiles/r05/stft_pmc.txt: the SIMDs'
+// issue ports are busy 88 % of the time; a packed fp32 instruction holds a
+// SIMD for 8 cycles, any other for 4), so the arithmetic is spelled as packed
+// instructions with operand modifiers (pk_* below): 180 arithmetic
+// instructions and no register moves a frame (round 4: 275 + 102).
 //
 // EPI 1: magnitude (B, 513, T)                         spectrogram.py:53
 // EPI 2: utterance maximum of 10 log10(max(1e-10, |X|^2)) only (no output)
