@@ -322,9 +322,9 @@ def kernel_label(name):
     m = re.search(r'conv_upsample_kernel<\w+,(\d+),', name)
     if m:
         return f'convT_c{m.group(1)}_r8'
-    if re.search(r'conv_single_kernel<\w+,2,3,64,4,2,1,2,0>', name):
+    if re.search(r'conv_single_kernel<\w+,2,3,64,4,2,1,\d,0>', name):
         return 'convT_c128_r2'
-    if re.search(r'conv_single_kernel<\w+,2,3,64,2,2,1,2,0>', name):
+    if re.search(r'conv_single_kernel<\w+,2,3,64,2,2,1,\d,0>', name):
         return 'convT_c64_r2'
     return None
 
@@ -725,11 +725,13 @@ def main():
     args = parse_args()
     if args.dtype is None:
         # (bf16: what BASELINE.json's batch-32 x 10 s config names; the
-        # library's own default is f16, promonet_amd/config.py)
-        # (fargan: arithmetic is fp32 in every mode; 'mixed' is the storage
-        # of the streamed weights - 6.4e-6 max-abs over a whole 10 s utterance
-        # against the 1e-4 gate; --dtype fp32 stores everything fp32)
-        args.dtype = 'mixed' if args.model == 'fargan' else 'bf16'
+        # library's own default operand mode, 'checkpoint', is in `secondary`)
+        # (fargan: arithmetic is fp32 in every mode; the flag is the STORAGE of
+        # the streamed weights and defaults to the library's default, 'fp32';
+        # --dtype mixed: GRU cells / GLU gates stored f16, 6.5e-6 max-abs over
+        # a whole 10 s utterance. Both are in the hifigan line's `secondary`)
+        args.dtype = promonet_amd.FARGAN_WEIGHT_DTYPE if args.model == 'fargan' \
+            else 'bf16'
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
     watchdog = Watchdog(float(os.environ.get('PROMONET_BENCH_HANG_SECONDS', 120)))

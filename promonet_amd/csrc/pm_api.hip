@@ -763,8 +763,12 @@ static int forward_impl(
             snprintf(label, sizeof(label), "convT_c%d_r%d", st.cin, st.r);
             PROF(h, s, label, 2.0 * st.cin * st.cout * st.k * B * L,
                  (double)B * L * (st.cin + (double)st.r * st.cout) * 4, {
-                HIP_TRY(launch_single(st.dtype, 1, st.up.geom.ch, st.up.cfg,
-                                      a, s));
+                // (long batches: the 256-column variant of cfg 3)
+                int cfg = st.up.cfg;
+                if (cfg == 3 && esz(st.dtype) == 2 && st.up.geom.ch == 64 &&
+                    (long long)B * ((L + 255) / 256) >= 4 * 256)
+                    cfg = 5;
+                HIP_TRY(launch_single(st.dtype, 1, st.up.geom.ch, cfg, a, s));
             });
         }
         L *= st.r;

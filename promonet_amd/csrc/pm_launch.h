@@ -608,6 +608,15 @@ static hipError_t launch_single_k(
             case 2: return launch_single_cfg<ET, KT, KSPAN, 64, 1, 4, 1, 1>(a, s);
             // all 128 rows of a 2x upsampler in one workgroup: x is read once
             case 3: return launch_single_cfg<ET, KT, KSPAN, 64, 4, 2, 1, 2>(a, s);
+            // the C_in = 128 r = 2 upsampler on long batches: 256 input columns
+            // a workgroup instead of 128 - half as many workgroups, a weight
+            // fragment feeds four MFMAs instead of two: 0.364 -> 0.342 ms (the
+            // same widening of cfg 1 for C_in = 64 measured neutral and is not
+            // kept: profiles/r05/ab_wide_upsampler.txt)
+            case 5:
+                if constexpr (KT == 2)
+                    return launch_single_cfg<ET, KT, KSPAN, 64, 4, 2, 1, 4>(a, s);
+                break;
         }
     } else if (ch == 32) {
         switch (cfg) {
