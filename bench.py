@@ -525,7 +525,7 @@ def secondary_hifigan(dtype, batch, seconds, device, steps=6, warmup=2):
     per-kernel pass for the dominant kernel and its MFMA fraction."""
     library = _lib.lib()
     previous = promonet_amd.COMPUTE_DTYPE
-    promonet_amd.configure(COMPUTE_DTYPE=dtype)
+    promonet_amd.configure(MODEL='hifigan', COMPUTE_DTYPE=dtype)
     try:
         torch.manual_seed(0)
         model = promonet_amd.model.Generator().to(device).eval()
@@ -605,7 +605,7 @@ def secondary_fargan(storage, device, batch=32, seconds=10., steps=2, warmup=1):
         promonet_amd.configure(MODEL='hifigan', FARGAN_WEIGHT_DTYPE=default)
 
 
-def secondary_preprocess(device, batch=32, seconds=10., reps=50):
+def secondary_preprocess(device, batch=32, seconds=10., reps=400):
     """spectrogram.from_audio, from_audio(mels=True) and loudness.from_audio
     (8 bands) of `batch` x `seconds` of audio through the C ABI on
     preallocated buffers (spectrogram.py:15-60,111-133; loudness.py:17-55):
@@ -645,7 +645,10 @@ def secondary_preprocess(device, batch=32, seconds=10., reps=50):
                     'through the C ABI, buffers preallocated',
         'dtype': 'fp32', 'reps': reps}
     for name, (call, nbytes, launches) in calls.items():
-        ms = time_events(call, reps, warmup=5)
+        # (hundreds of back-to-back launches after a long warm-up: a burst of
+        # 50 of these 40 us kernels reads 10 % high - the clocks are still
+        # settling from the model builds in front of it)
+        ms = time_events(call, reps, warmup=100)
         gbs = nbytes / (ms * 1e-3) / 1e9
         out[name] = {
             'ms': ms, 'kernel_launches': launches,
@@ -1153,7 +1156,9 @@ def main():
                     'tflops': v['flops'] / max(v['ms'], 1e-9) / 1e9,
                     'gbs': v['bytes'] / max(v['ms'], 1e-9) / 1e6}
                 for k, v in sorted(profile.items())}
-        if world == 1 and not stand_in and not args.no_secondary:
+        # (the secondary block rides on the HiFi-GAN headline line only: it
+        # builds its own models under the default configuration)
+        if world == 1 and hifigan and not args.no_secondary:
             # (the headline model's workspace goes back to the allocator first)
             del model, inputs
             torch.cuda.empty_cache()

@@ -27,9 +27,9 @@ def label(kernel):
     m = re.match(r'conv_upsample_kernel<\w+,(\d+),', kernel)
     if m:
         return f'convT_c{m.group(1)}_r8'
-    if re.match(r'conv_single_kernel<\w+,2,3,64,4,2,1,2,0>', kernel):
+    if re.match(r'conv_single_kernel<\w+,2,3,64,4,2,1,\d,0>', kernel):
         return 'convT_c128_r2'
-    if re.match(r'conv_single_kernel<\w+,2,3,64,2,2,1,2,0>', kernel):
+    if re.match(r'conv_single_kernel<\w+,2,3,64,2,2,1,\d,0>', kernel):
         return 'convT_c64_r2'
     return None
 
