@@ -74,6 +74,47 @@ def device_identity(index):
     return ' '.join(parts)
 
 
+def decide_backend(entries, local_world, devices, use_gpu, wanted=None):
+    """The data plane's backend from what the ranks published (`entries`: one
+    {'rank', 'host', 'id', ...} per rank). Returns (backend, shared, note):
+    `shared` maps (host, device id) to the ranks that sit on it together,
+    `note` is the loud fallback message or None. Pure function of its
+    arguments (tests/test_cpu_distributed.py drives every branch).
+      all devices different                     -> 'nccl' (RCCL)
+      shared, more local ranks than GPUs        -> 'gloo', with a note
+      shared, although every rank could own one -> RuntimeError
+      `wanted` forces a backend ('nccl' on shared devices -> RuntimeError)"""
+    if wanted not in (None, 'nccl', 'gloo'):
+        raise ValueError(f'unknown backend {wanted}')
+    owners = {}
+    for entry in entries:
+        owners.setdefault((entry['host'], entry['id']), []).append(
+            entry['rank'])
+    shared = {k: v for k, v in owners.items() if len(v) > 1} if use_gpu else {}
+    note = None
+    if shared and wanted != 'gloo':
+        text = '; '.join(
+            f'ranks {ranks} on {host} share {ident}'
+            for (host, ident), ranks in sorted(shared.items()))
+        if wanted == 'nccl':
+            raise RuntimeError(
+                f'promonet_amd.distributed.init: backend nccl asked for but '
+                f'{text} (RCCL refuses two ranks on one device)')
+        if local_world <= devices:
+            raise RuntimeError(
+                f'promonet_amd.distributed.init: {text} although {devices} '
+                f'GPUs are visible for {local_world} local ranks - LOCAL_RANK '
+                'mis-set? Refusing to fall back to host-staged gloo '
+                'collectives for a job that could run one rank per GPU over '
+                'RCCL.')
+        note = (
+            f'{text}: {local_world} local ranks on {devices} visible GPU(s) - '
+            'data plane over gloo, staged through host memory (test-box mode; '
+            'NOT a scaling measurement)')
+    chosen = wanted or ('nccl' if use_gpu and not shared else 'gloo')
+    return chosen, shared, note
+
+
 def init(backend=None, force=False, timeout=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE /
     LOCAL_RANK / MASTER_ADDR / MASTER_PORT). Returns (rank, world, device).
@@ -119,37 +160,13 @@ def init(backend=None, force=False, timeout=None):
             'name': torch.cuda.get_device_name(index) if use_gpu else 'cpu'}
         every = [None] * world
         dist.all_gather_object(every, mine)
-        owners = {}
-        for entry in every:
-            owners.setdefault((entry['host'], entry['id']), []).append(
-                entry['rank'])
-        shared = {k: v for k, v in owners.items() if len(v) > 1} \
-            if use_gpu else {}
-        wanted = backend or os.environ.get('PROMONET_DIST_BACKEND')
-        note = None
-        if shared and wanted != 'gloo':
-            text = '; '.join(
-                f'ranks {ranks} on {host} share {ident}'
-                for (host, ident), ranks in sorted(shared.items()))
-            if wanted == 'nccl':
-                raise RuntimeError(
-                    f'promonet_amd.distributed.init: backend nccl asked for '
-                    f'but {text} (RCCL refuses two ranks on one device)')
-            if local_world <= devices:
-                raise RuntimeError(
-                    f'promonet_amd.distributed.init: {text} although '
-                    f'{devices} GPUs are visible for {local_world} local '
-                    'ranks - LOCAL_RANK mis-set? Refusing to fall back to '
-                    'host-staged gloo collectives for a job that could run '
-                    'one rank per GPU over RCCL.')
-            note = (
-                f'{text}: {local_world} local ranks on {devices} visible '
-                'GPU(s) - data plane over gloo, staged through host memory '
-                '(test-box mode; NOT a scaling measurement)')
+        chosen, shared, note = decide_backend(
+            every, local_world, devices, use_gpu,
+            backend or os.environ.get('PROMONET_DIST_BACKEND'))
+        if note:
             sys.stderr.write(
                 f'promonet_amd.distributed [rank {rank}]: WARNING: {note}\n')
             sys.stderr.flush()
-        chosen = wanted or ('nccl' if use_gpu and not shared else 'gloo')
         group = None
         if chosen == 'nccl':
             group = dist.new_group(backend='nccl', **extra)

@@ -144,3 +144,48 @@ def test_single_process_is_a_no_op():
     assert distributed.all_gather_audio(audio, 3) is audio
     model = torch.nn.Linear(2, 2)
     assert distributed.broadcast_model(model) is model
+
+
+def test_backend_is_decided_from_the_devices():
+    """`distributed.decide_backend`: what carries the weight broadcast and the
+    audio all-gather follows from the physical devices the ranks bound."""
+    import pytest
+
+    def ranks(ids, host='node'):
+        return [{'rank': r, 'host': host, 'index': 0, 'id': i, 'name': 'gpu'}
+                for r, i in enumerate(ids)]
+
+    # eight ranks, eight GPUs: RCCL, nothing to report
+    chosen, shared, note = distributed.decide_backend(
+        ranks([f'pci:00:{b:02x}:00' for b in range(8)]), 8, 8, True)
+    assert (chosen, shared, note) == ('nccl', {}, None)
+    # every rank sees ONE isolated GPU as cuda:0 (a launcher that masks
+    # devices per rank): different identities, still RCCL
+    chosen, shared, note = distributed.decide_backend(
+        ranks([f'uuid:{b}' for b in range(8)]), 8, 1, True)
+    assert chosen == 'nccl' and note is None
+    # the same PCI address on two HOSTS is two devices
+    entries = ranks(['pci:00:0c:00']) + [dict(ranks(['pci:00:0c:00'], 'other')[0], rank=1)]
+    assert distributed.decide_backend(entries, 1, 1, True)[0] == 'nccl'
+    # two ranks folded onto the test box's one GPU: gloo, and it says so
+    chosen, shared, note = distributed.decide_backend(
+        ranks(['pci:00:0c:00'] * 2), 2, 1, True)
+    assert chosen == 'gloo' and shared == {('node', 'pci:00:0c:00'): [0, 1]}
+    assert 'NOT a scaling measurement' in note and 'ranks [0, 1]' in note
+    # a mis-set LOCAL_RANK (two ranks on one of eight GPUs): refused, never a
+    # silent host-staged run
+    with pytest.raises(RuntimeError, match='LOCAL_RANK'):
+        distributed.decide_backend(
+            ranks(['pci:00:0c:00'] * 2 + [f'pci:00:{b:02x}:00' for b in range(6)]),
+            8, 8, True)
+    # forcing: gloo always allowed; nccl on a shared device refused
+    assert distributed.decide_backend(
+        ranks(['a', 'a']), 2, 1, True, 'gloo') == (
+            'gloo', {('node', 'a'): [0, 1]}, None)
+    with pytest.raises(RuntimeError, match='RCCL refuses'):
+        distributed.decide_backend(ranks(['a', 'a']), 2, 1, True, 'nccl')
+    with pytest.raises(ValueError):
+        distributed.decide_backend(ranks(['a']), 1, 1, True, 'mpi')
+    # CPU ranks (no GPU): gloo, identical 'cpu' identities are not "shared"
+    assert distributed.decide_backend(ranks(['cpu'] * 4), 4, 0, False) == (
+        'gloo', {}, None)
