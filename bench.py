@@ -794,7 +794,14 @@ def main():
         drain()
         sync(device)
         if world > 1:
-            dist.barrier()          # (the gloo control group)
+            # (over RCCL when it carries the data plane: a device-side barrier
+            # of tens of microseconds inside the timed region instead of a
+            # host-side gloo one of up to a millisecond at 8 ranks)
+            if backend == 'nccl':
+                dist.barrier(group=promonet_amd.distributed.data_group(),
+                             device_ids=[device.index])
+            else:
+                dist.barrier()
             sync(device)
 
     library = None if stand_in else _lib.lib()

@@ -216,8 +216,12 @@ def config4_worker(rank, world, port, backend, results):
             single = model(*[t[item:item + 1] for t in theirs], None)
             assert torch.equal(single[0], gathered[pick]), pick
     results.put((rank, float(gathered.abs().max()), gathered.shape[0]))
+    if backend == 'nccl':
+        # bench.py's fence(): a device-side barrier on the RCCL data group
+        dist.barrier(group=distributed.data_group(), device_ids=[device.index])
+        torch.cuda.synchronize()
     dist.barrier()
-    dist.destroy_process_group()
+    distributed.shutdown()
 
 
 def run_config4(world, backend):
