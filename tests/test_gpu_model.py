@@ -905,3 +905,61 @@ def test_packed_inference_graph(device, default_state, dtype):
     zeros = model.packed_inference(
         torch.zeros(1, 53, 32, device=device), graph=True)
     assert tuple(zeros.shape) == (1, 1, 8192) and torch.isfinite(zeros).all()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'checkpoint'])
+def test_full_size_shift_equivariance(device, default_state, dtype):
+    """A size-independent property at BASELINE.json's full size (batch 32 x
+    861 frames), no oracle needed: the generator is convolutional
+    (hifigan.py:63-70; prepare_features is per frame), so conditioning shifted
+    by k frames gives the same audio shifted by 256 k samples - BIT FOR BIT
+    away from the edges (the receptive field is 14 frames a side),
+    whatever tile, segment or walk step a column falls into after the shift:
+    every tiling computes a column with the same arithmetic."""
+    model = make_model(default_state, dtype, device)
+    frames, shift, field = 861, 37, 16
+    inputs = on(device, oracle.synthetic_inputs(32, frames + shift, seed=77))
+    early = [t[..., :frames].contiguous() if t.ndim >= 2 else t for t in inputs]
+    late = [t[..., shift:].contiguous() if t.ndim >= 2 else t for t in inputs]
+    with torch.inference_mode():
+        a = model(*early, None)
+        b = model(*late, None)
+    assert a.shape == b.shape == (32, 1, frames * 256)
+    # frames [shift + field, frames - field) of `early` = frames
+    # [field, frames - shift - field) of `late`
+    lo, hi = (shift + field) * 256, (frames - field) * 256
+    same = torch.equal(a[..., lo:hi], b[..., lo - shift * 256:hi - shift * 256])
+    worst = (a[..., lo:hi] - b[..., lo - shift * 256:hi - shift * 256]).abs().max()
+    print(f'shift equivariance {dtype}: interior of {hi - lo} samples x 32 '
+          f'utterances, max difference {worst.item():.3e}')
+    assert same
+    # and the edges DO differ (the test would pass trivially on constant audio)
+    assert not torch.equal(a[..., :lo], b[..., :lo])
+
+
+def test_full_size_stft_parseval(device):
+    """Size-independent property of the STFT at the benchmarked size, against
+    nothing but the input: Parseval for the real 1024-point transform of a
+    windowed frame, sum_n (w x)^2 = (|X_0|^2 + |X_512|^2 + 2 sum_{0<k<512}
+    |X_k|^2) / 1024, for every one of the 27 552 frames (the kernel's
+    magnitude is sqrt(|X|^2 + 1e-6): removed before summing)."""
+    import promonet_amd
+    gen = torch.Generator().manual_seed(123)
+    batch, frames = 32, 861
+    audio = torch.randn(batch, frames * 256, generator=gen) * .1
+    audio *= (10. ** (-(torch.arange(batch) % 5) / 2.))[:, None]
+    spec = promonet_amd.preprocess.spectrogram.from_audio(
+        audio.to(device)[:, None]).double().cpu()
+    power = spec ** 2 - 1e-6
+    weight = torch.full((513, 1), 2., dtype=torch.float64)
+    weight[0] = weight[512] = 1.
+    spectral = (power * weight).sum(1) / 1024.
+    padded = torch.nn.functional.pad(
+        audio.double()[:, None], (384, 384), mode='reflect')[:, 0]
+    window = torch.hann_window(1024, dtype=torch.float64)
+    temporal = (padded.unfold(-1, 1024, 256) * window).pow(2).sum(-1)
+    assert spectral.shape == temporal.shape == (batch, frames)
+    relative = ((spectral - temporal).abs() / temporal).max().item()
+    print(f'Parseval over {batch * frames} frames: worst relative {relative:.3e}')
+    # (measured 1.4e-7)
+    check(relative, 5e-7, 'stft_parseval_full_size')
