@@ -440,7 +440,6 @@ void pm_stft_fft_kernel(FftArgs a) {
                 u = u < a.min_db ? a.min_db : u;
                 if (lane == 0) {
                     bs[7] += bs[6]; bs[6] = bs[5]; bs[5] = bs[4]; bs[4] = u;
-                    bs[4] += 0.f;
                 }
             } else if (lane == 0) {
                 bin_out(pw4, 256, w256, 4);
