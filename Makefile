@@ -41,7 +41,7 @@ clean:
 	rm -rf build $(LIB)
 
 # Micro-benchmarks behind DESIGN.md section 6 (run the binaries on the GPU box)
-MICRO = mfma_peak mfma_shapes mma_loop phase_overlap overlap2 lds_dma
+MICRO = mfma_peak mfma_shapes mma_loop phase_overlap overlap2 lds_dma xcd_exchange
 micro: $(addprefix promonet_amd/lib/,$(MICRO))
 promonet_amd/lib/%: scripts/micro/%.hip promonet_amd/csrc/pm_conv.h
 	$(HIPCC) $(CXXFLAGS) -Wno-unused-result $< -o $@
