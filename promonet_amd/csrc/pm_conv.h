@@ -174,6 +174,9 @@ __device__ __forceinline__ void mma_taps(
     const typename ET::frag_t* __restrict__ wnext, Hook mid = Hook()) {
     typedef typename ET::frag_t frag_t;
     constexpr int NS = KT * KC;
+#if defined(PM_TUNING) && defined(PM_ABLATE_MMA)   // timing experiment only: no MFMA loops
+    return;
+#endif
     // (split-f16: fragments are twice as wide and a step is three MFMAs per
     // tile; the second B buffer is what spilled in the whole-MRF kernel, and
     // the SIMD's other wave covers the LDS round trip)
@@ -367,6 +370,9 @@ template <class ET>
 __device__ __forceinline__ void store_tile_lrelu(
     char* rowp, const int ch, const floatx16& v, const int t_tile,
     const int L, const int ln, const int lh) {
+#if defined(PM_TUNING) && defined(PM_ABLATE_EPI)   // timing experiment only: no epilogue stores
+    return;
+#endif
     if (t_tile >= 0 && t_tile + 32 <= L) {
         store_tile_lrelu_impl<ET, false>(rowp, ch, v, false, lh);
     } else {
@@ -1176,6 +1182,9 @@ __device__ __forceinline__ void block3_body(
     [[maybe_unused]] auto strip_copy2 = [&](
         char* dst_a, const char* src_a, int rows_a, char* dst_b,
         const char* src_b, int rows_b) {
+#if defined(PM_TUNING) && defined(PM_ABLATE_STRIP)   // timing experiment only: no carries
+        return;
+#endif
         const int na = rows_a * QS16, nb = rows_b * QS16;
         for (int i = tid; i < na + nb; i += NT) {
             const bool second = i >= na;
@@ -1195,20 +1204,22 @@ __device__ __forceinline__ void block3_body(
         float zero = 0.f;
         if constexpr (WALK) asm volatile("" : "+v"(zero));
         const float4 z = make_float4(zero, zero, zero, zero);
+        // (walked: the last H2 d_0 rows of the left margin are the previous
+        // tile's last columns of a_0 = lrelu(x), from the carry area - written
+        // by the thread that would have zeroed them: two loops over the margin
+        // put the zero and the carried value of one address in different waves
+        // with nothing but their arrival order between them)
+        int first_carried = MA * QS;
+        if constexpr (WALK)
+            if (wk->left) first_carried = (MA - H2 * wk->dil[0]) * QS;
         for (int i = tid; i < (WALK ? 1 : 2) * MA * QS; i += NT) {
             const int r = i / QS, q = i % QS;
             const int row = r < MA ? r : NC + r;
-            *reinterpret_cast<float4*>(abuf + row * S + q * 16) = z;
-        }
-        if constexpr (WALK) {
-            // (same threads, same addresses as the zero fill above: program
-            // order) the previous tile's last H2 d_0 columns of a_0 = lrelu(x)
-            if (wk->left) {
-                const int ma = H2 * wk->dil[0];
-                for (int i = tid; i < ma * QS; i += NT)
-                    reinterpret_cast<float4*>(abuf + (MA - ma) * S)[i] =
-                        reinterpret_cast<const float4*>(wk->carry)[i];
-            }
+            float4 v = z;
+            if constexpr (WALK)
+                if (i >= first_carried)
+                    v = reinterpret_cast<const float4*>(wk->carry)[i - first_carried];
+            *reinterpret_cast<float4*>(abuf + row * S + q * 16) = v;
         }
         // (walked: no right margin behind `t` either - what lies behind it,
         // the carry area, is finite and only reaches right-halo columns)
@@ -1451,6 +1462,9 @@ __device__ __forceinline__ void block3_body(
     // Buffer accesses over a descriptor of exactly the rows this tile owns:
     // halo columns and columns beyond the utterance are out of range (stores
     // dropped, loads 0) - no per-lane branches.
+#if defined(PM_TUNING) && defined(PM_ABLATE_OUT)   // timing experiment only: nothing stored
+    if (trunk[0][0][0] != 12345.f) return;
+#endif
     const int mode = SUM == 3 ? 1 : a.mode;
     const float scale = a.scale;
     const int own_first = c_first + store_lo;

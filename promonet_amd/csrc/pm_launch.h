@@ -18,8 +18,13 @@
 #ifndef PM_X3SKEW_F32
 #define PM_X3SKEW_F32 1
 #endif
+// (A/B builds: -DPM_SKEW16_C32=1 sends the 16-bit C = 32 stage the same way)
+#ifndef PM_SKEW16_C32
+#define PM_SKEW16_C32 0
+#endif
 constexpr bool pm_x3skew_id(int id) {
-    return id == 3 || (PM_X3SKEW_F32 && id == 0);
+    return id == 3 || (PM_X3SKEW_F32 && id == 0) ||
+           (PM_SKEW16_C32 && (id == 1 || id == 2));
 }
 
 // Opt a kernel into `bytes` of dynamic LDS (> 48 KB needs the attribute).
@@ -261,8 +266,8 @@ template <class ET, int C, int K> struct Block3Cfg { enum { WM = 0, WN = 1, NTW 
 // at C = 32 k 3, -5 % at C = 32 k 7, -13 % at C = 64 k 3. With a larger halo
 // (k 11, or k 7 at C = 64) the extra recompute eats the gain; at C = 128 it is
 // 28 % slower.
-template <> struct Block3Cfg<ElemF16, 32, 3>   { enum { WM = 1, WN = 4, NTW = 3 }; };
-template <> struct Block3Cfg<ElemF16, 32, 7>   { enum { WM = 1, WN = 4, NTW = 3 }; };
+template <> struct Block3Cfg<ElemF16, 32, 3>   { enum { WM = 1, WN = PM_SKEW16_C32 ? 8 : 4, NTW = 3 }; };
+template <> struct Block3Cfg<ElemF16, 32, 7>   { enum { WM = 1, WN = PM_SKEW16_C32 ? 8 : 4, NTW = 3 }; };
 template <> struct Block3Cfg<ElemF16, 32, 11>  { enum { WM = 1, WN = 8, NTW = 3 }; };
 template <> struct Block3Cfg<ElemF16, 64, 3>   { enum { WM = 2, WN = 2, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 64, 7>   { enum { WM = 2, WN = 4, NTW = 4 }; };
@@ -319,7 +324,8 @@ static hipError_t launch_block3_cfg(const Block3Args& a0, hipStream_t stream) {
     // MFMA-bound at three MFMAs per step, so what the skew removes - the 23 %
     // halo of the stand-alone whole-MRF tiling - shows: three skewed Block
     // launches 6.07 ms against 6.99 ms fused, profiles/r04/ab_x3_skew.txt)
-    constexpr bool X3SKEW = pm_x3skew_id(ET::ID) && (C == 32 || C == 64);
+    constexpr bool X3SKEW = pm_x3skew_id(ET::ID) &&
+                            (C == 32 || (C == 64 && ET::ESZ == 4));
     if constexpr ((ET::ESZ == 2 || X3SKEW) && WM * WN == 8 && NTW >= 2) {
         typedef SkewGeom<ET, C, K, WM, WN, NTW> GE;
         static_assert(GE::SCRATCH <= PM_SKEW_WG_SCRATCH, "scratch bound");
