@@ -12,7 +12,7 @@ SRC = promonet_amd/csrc
 OBJ = build/obj
 LIB = promonet_amd/lib/libpromonet_hip.so
 OBJS = $(OBJ)/pm_api.o $(OBJ)/pm_conv_f16.o $(OBJ)/pm_conv_bf16.o $(OBJ)/pm_conv_f32.o \
-       $(OBJ)/pm_conv_f16x3.o \
+       $(OBJ)/pm_conv_f16x3.o $(OBJ)/pm_conv_f16a2.o \
        $(OBJ)/pm_conv_f16_mrf.o $(OBJ)/pm_conv_bf16_mrf.o
 # the whole-MRF kernels: see pm_conv_bf16_mrf.hip
 MRF_FLAGS = -mllvm -amdgpu-sched-strategy=max-ilp

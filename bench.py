@@ -66,7 +66,7 @@ FARGAN_COND_WEIGHTS = 2 * 371 * 371 + 512 * 371
 FARGAN_MIXED_F16_WEIGHTS = 3 * 768 * 640 + 5 * 256 * 256
 # dense MFMA peaks per USEFUL flop (f16x3: three MFMAs per product)
 PEAK_TFLOPS = {'f16': 2500., 'bf16': 2500., 'fp32': 157.3,
-               'f16x3': 2500. / 3}
+               'f16x3': 2500. / 3, 'f16a2': 2500. / 2}
 PEAK_HBM_GBS = 8000.
 # (the SUSTAINED rate of the matrix pipe under this device's power cap is
 # measured in the run: mfma_probe below)
@@ -285,12 +285,20 @@ def operand_type_of(label, dtype):
     import re
     parts = dtype.split('+')
     if parts == ['checkpoint']:
-        parts = ['f16', 'f16', 'f16', 'f16x3']
+        from promonet_amd.model.hifigan import checkpoint_schedule
+        parts = checkpoint_schedule(4)
+
+    def resolve(name, upsampler):
+        # a stage's type names its Blocks; 'f16a2' / 'f16ux' stages run their
+        # upsampler fully split (promonet_hip.h)
+        if name in ('f16a2', 'f16ux'):
+            return 'f16x3' if upsampler else {'f16ux': 'f16'}.get(name, name)
+        return name
     if len(parts) == 1:
-        return parts[0]
+        return resolve(parts[0], label.startswith('convT'))
     match = re.search(r'_c(\d+)', label)
     if not match:
-        return parts[0]
+        return resolve(parts[0], False)
     channels = int(match.group(1))
     initial = promonet_amd.HIFIGAN_UPSAMPLE_INITIAL_SIZE
     for stage in range(len(parts)):
@@ -298,8 +306,8 @@ def operand_type_of(label, dtype):
         width = initial >> stage if label.startswith('convT') \
             else initial >> (stage + 1)
         if width == channels:
-            return parts[stage]
-    return parts[0]
+            return resolve(parts[stage], label.startswith('convT'))
+    return resolve(parts[0], False)
 
 
 def kernel_label(name):
@@ -437,8 +445,8 @@ def mfma_probe(operand, device, target_ms=50.):
     """The matrix pipe's sustained rate on this device, now: a register-resident
     loop of v_mfma_f32_32x32x16 (pm_mfma_probe), sized to ~`target_ms`, timed
     with HIP events. Returns TFLOP/s or None (operand type without a probe)."""
-    code = {'f16': _lib.PM_F16, 'bf16': _lib.PM_BF16, 'f16x3': _lib.PM_F16}.get(
-        operand)
+    code = {'f16': _lib.PM_F16, 'bf16': _lib.PM_BF16, 'f16x3': _lib.PM_F16,
+            'f16a2': _lib.PM_F16}.get(operand)
     if code is None:
         return None
     library = _lib.lib()

@@ -48,6 +48,13 @@ extern "C" {
 #define PM_F16X3 3          /* f16 operands split hi + lo, three MFMAs per
                              * step: ~21 bits per factor (trained-scale
                              * accuracy for the last stage)  */
+#define PM_F16A2 4          /* f16 operands, the ACTIVATIONS split hi + lo
+                             * (two MFMAs per step, f16 weight stream). As
+                             * the type of a STAGE: its Blocks; the stage's
+                             * upsampler - one rounding of a wide sum - runs
+                             * PM_F16X3                                    */
+#define PM_F16UX 5          /* stage / engine type only: f16 Blocks behind a
+                             * PM_F16X3 upsampler                          */
 
 #define PM_MAX_STAGES 8
 #define PM_MAX_RESBLOCKS 4
@@ -68,9 +75,9 @@ typedef struct pm_hifigan_config {
     int resblock_kernel_sizes[PM_MAX_RESBLOCKS];
     int num_dilations;
     int resblock_dilations[PM_MAX_RESBLOCKS][PM_MAX_DILATIONS];
-    int compute_dtype;                /* PM_F32 | PM_F16 | PM_BF16 | PM_F16X3 */
+    int compute_dtype;                /* PM_F32 ... PM_F16UX                 */
     /* Per-stage override of the MFMA operand type (upsampler + MRF of stage
-     * i): 0 = compute_dtype, else 1 + PM_F32 | PM_F16 | PM_BF16 | PM_F16X3. E.g. bf16
+     * i): 0 = compute_dtype, else 1 + PM_F32 ... PM_F16UX. E.g. bf16
      * for the wide stages and f16 for the last two, whose rounding reaches
      * the output most directly.                                           */
     int stage_compute_dtype[PM_MAX_STAGES];

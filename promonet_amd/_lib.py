@@ -11,9 +11,10 @@ import torch
 
 LIB_PATH = Path(__file__).parent / 'lib' / 'libpromonet_hip.so'
 
-PM_F32, PM_F16, PM_BF16, PM_F16X3 = 0, 1, 2, 3
+PM_F32, PM_F16, PM_BF16, PM_F16X3, PM_F16A2, PM_F16UX = 0, 1, 2, 3, 4, 5
 DTYPES = {'fp32': PM_F32, 'f32': PM_F32, 'f16': PM_F16, 'fp16': PM_F16,
-          'bf16': PM_BF16, 'f16x3': PM_F16X3,
+          'bf16': PM_BF16, 'f16x3': PM_F16X3, 'f16a2': PM_F16A2,
+          'f16ux': PM_F16UX,
           # FARGAN weight storage only (PM_FARGAN_MIXED, promonet_hip.h):
           # GRU cells / GLU gates f16, the rounding-sensitive layers fp32
           'mixed': 16}

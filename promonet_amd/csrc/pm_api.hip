@@ -50,8 +50,18 @@ static unsigned long long* g_timeline = nullptr;   // pm_debug_timeline
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+// bytes per element of an LDS operand row / of a packed weight stream
 static inline int esz(int dtype) {
+    return dtype == PM_F32 || dtype == PM_F16X3 || dtype == PM_F16A2 ? 4 : 2;
+}
+static inline int wsz(int dtype) {
     return dtype == PM_F32 || dtype == PM_F16X3 ? 4 : 2;
+}
+// A stage's (or the engine's) operand type code -> the type of its Blocks and
+// of its upsampler (promonet_hip.h: PM_F16A2, PM_F16UX)
+static inline int block_dtype(int code) { return code == PM_F16UX ? PM_F16 : code; }
+static inline int up_dtype(int code) {
+    return code == PM_F16A2 || code == PM_F16UX ? PM_F16X3 : code;
 }
 
 // ---------------------------------------------------------------------------
@@ -68,6 +78,7 @@ static hipError_t launch_pair(
         case PM_F16: return pm_launch_pair<ElemF16>(C, K, a, s);
         case PM_BF16: return pm_launch_pair<ElemBF16>(C, K, a, s);
         case PM_F16X3: return pm_launch_pair<ElemF16X3>(C, K, a, s);
+        case PM_F16A2: return pm_launch_pair<ElemF16A2>(C, K, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -83,6 +94,7 @@ static hipError_t launch_block3(
         case PM_F16: return pm_launch_block3<ElemF16>(C, K, a, s);
         case PM_BF16: return pm_launch_block3<ElemBF16>(C, K, a, s);
         case PM_F16X3: return pm_launch_block3<ElemF16X3>(C, K, a, s);
+        case PM_F16A2: return pm_launch_block3<ElemF16A2>(C, K, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -94,6 +106,7 @@ static hipError_t launch_mrf(
         case PM_F16: return pm_launch_mrf<ElemF16>(C, a, s);
         case PM_BF16: return pm_launch_mrf<ElemBF16>(C, a, s);
         case PM_F16X3: return pm_launch_mrf<ElemF16X3>(C, a, s);
+        case PM_F16A2: return pm_launch_mrf<ElemF16A2>(C, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -122,6 +135,7 @@ static int pair_chunk(int dtype, int C) {
         case PM_F16: return pm_pair_chunk<ElemF16>(C);
         case PM_BF16: return pm_pair_chunk<ElemBF16>(C);
         case PM_F16X3: return pm_pair_chunk<ElemF16X3>(C);
+        case PM_F16A2: return pm_pair_chunk<ElemF16A2>(C);
     }
     return 0;
 }
@@ -133,6 +147,7 @@ static bool block3_supported(int dtype, int C, int K) {
         case PM_F16: return pm_block3_supported<ElemF16>(C, K);
         case PM_BF16: return pm_block3_supported<ElemBF16>(C, K);
         case PM_F16X3: return pm_block3_supported<ElemF16X3>(C, K);
+        case PM_F16A2: return pm_block3_supported<ElemF16A2>(C, K);
     }
     return false;
 }
@@ -151,6 +166,7 @@ static hipError_t launch_single(
         case PM_F16: return pm_launch_single<ElemF16>(kind, ch, cfg, a, s);
         case PM_BF16: return pm_launch_single<ElemBF16>(kind, ch, cfg, a, s);
         case PM_F16X3: return pm_launch_single<ElemF16X3>(kind, ch, cfg, a, s);
+        case PM_F16A2: return pm_launch_single<ElemF16A2>(kind, ch, cfg, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -169,6 +185,9 @@ static hipError_t launch_pack(int dtype, const PackArgs& a, hipStream_t s) {
             break;
         case PM_F16X3:
             hipLaunchKernelGGL(pm_pack_kernel<ElemF16X3>, dim3(grid), dim3(256), 0, s, a);
+            break;
+        case PM_F16A2:
+            hipLaunchKernelGGL(pm_pack_kernel<ElemF16A2>, dim3(grid), dim3(256), 0, s, a);
             break;
         default:
             return hipErrorInvalidValue;
@@ -226,6 +245,10 @@ static hipError_t pack_bias_step(
             break;
         case PM_F16X3:
             hipLaunchKernelGGL(pm_pack_bias_step_kernel<ElemF16X3>, grid, block,
+                               0, s, bias, out, g.cout, mtiles, per_mt);
+            break;
+        case PM_F16A2:
+            hipLaunchKernelGGL(pm_pack_bias_step_kernel<ElemF16A2>, grid, block,
                                0, s, bias, out, g.cout, mtiles, per_mt);
             break;
         default:
@@ -343,7 +366,7 @@ extern "C" const char* pm_last_error(void) { return g_error; }
 extern "C" int pm_hifigan_create(
     const pm_hifigan_config* c, pm_hifigan_t* out) {
     if (!c || !out) return fail(PM_EINVAL, "null argument");
-    if (c->compute_dtype < 0 || c->compute_dtype > PM_F16X3)
+    if (c->compute_dtype < 0 || c->compute_dtype > PM_F16UX)
         return fail(PM_EINVAL, "compute_dtype %d unknown", c->compute_dtype);
     if (c->num_stages < 1 || c->num_stages > PM_MAX_STAGES ||
         c->num_resblocks < 1 || c->num_resblocks > PM_MAX_RESBLOCKS ||
@@ -365,13 +388,13 @@ extern "C" int pm_hifigan_create(
     }
     for (int i = 0; i < c->num_stages; ++i)
         if (c->stage_compute_dtype[i] < 0 ||
-            c->stage_compute_dtype[i] > 1 + PM_F16X3)
+            c->stage_compute_dtype[i] > 1 + PM_F16UX)
             return fail(PM_EINVAL, "stage_compute_dtype[%d] = %d unknown", i,
                         c->stage_compute_dtype[i]);
     auto* h = new pm_hifigan_s();
     h->cfg = *c;
     h->dtype = c->compute_dtype;
-    h->in_conv.dtype = h->dtype;
+    h->in_conv.dtype = block_dtype(h->dtype);
     h->cfp = pad32(c->num_features);
     h->c0 = c->initial_channels;
     h->c0p = pad32(h->c0);
@@ -381,9 +404,10 @@ extern "C" int pm_hifigan_create(
         Stage& s = h->stages[i];
         s.r = c->upsample_rates[i];
         s.k = c->upsample_kernel_sizes[i];
-        s.dtype = c->stage_compute_dtype[i] ? c->stage_compute_dtype[i] - 1
-                                            : h->dtype;
-        s.up.dtype = s.dtype;
+        const int code = c->stage_compute_dtype[i]
+            ? c->stage_compute_dtype[i] - 1 : h->dtype;
+        s.dtype = block_dtype(code);
+        s.up.dtype = up_dtype(code);
         if (s.r < 2 || (s.r & 1) || s.k != 2 * s.r) {
             delete h;
             return fail(PM_EINVAL,
@@ -409,7 +433,7 @@ extern "C" int pm_hifigan_create(
         g.cout_pad = s.cout_pad; g.cin_pad = s.cin_pad;
         g.M = s.r * s.cout_pad; g.kt = 2; g.r = s.r; g.p = s.r / 2;
         g.ch = (s.cin_pad % 64 == 0) ? 64 : 32;
-        s.up.cfg = upsample_whole_k(s.dtype, g)
+        s.up.cfg = upsample_whole_k(s.up.dtype, g)
             ? 4
             : single_cfg(g.M, g.ch, ((s.r / 2) * s.cout_pad) % 64 == 0);
         for (int j = 0; j < c->num_resblocks; ++j)
@@ -484,7 +508,7 @@ static int set_weight(
     if (ndim != 3 || shape[0] != d0 || shape[1] != d1 || shape[2] != g.k)
         return fail(PM_EINVAL, "%s: expected shape (%lld, %lld, %d)", name,
                     (long long)d0, (long long)d1, g.k);
-    const size_t bytes = g.packed_elems() * esz(l.dtype);
+    const size_t bytes = g.packed_elems() * wsz(l.dtype);
     if (!l.w) HIP_TRY(hipMalloc(&l.w, bytes));
     HIP_TRY(pack_weights(l.dtype, g, w, l.w, s));
     l.has_w = true;
@@ -765,10 +789,10 @@ static int forward_impl(
                  (double)B * L * (st.cin + (double)st.r * st.cout) * 4, {
                 // (long batches: the 256-column variant of cfg 3)
                 int cfg = st.up.cfg;
-                if (cfg == 3 && esz(st.dtype) == 2 && st.up.geom.ch == 64 &&
+                if (cfg == 3 && esz(st.up.dtype) == 2 && st.up.geom.ch == 64 &&
                     (long long)B * ((L + 255) / 256) >= 4 * 256)
                     cfg = 5;
-                HIP_TRY(launch_single(st.dtype, 1, st.up.geom.ch, cfg, a, s));
+                HIP_TRY(launch_single(st.up.dtype, 1, st.up.geom.ch, cfg, a, s));
             });
         }
         L *= st.r;
@@ -845,9 +869,9 @@ static int forward_impl(
                 if (j == h->cfg.num_resblocks - 1 && a.mode == 2 &&
                     si_index + 1 < h->stages.size()) {
                     const Stage& next = h->stages[si_index + 1];
-                    if (esz(next.dtype) == 2 && next.up.cfg != 4) {
+                    if (esz(next.up.dtype) == 2 && next.up.cfg != 4) {
                         a.act16 = buf[ai];      // (free: no pair iterations)
-                        a.act16_type = next.dtype;
+                        a.act16_type = next.up.dtype;
                         a.act16_done = &act16_done;
                     }
                 }

@@ -61,8 +61,12 @@ __device__ __forceinline__ float4 pm_lrelu4(float4 v) {
 struct ElemF16 {
     typedef _Float16 lds_t;
     typedef half8 frag_t;
-    static constexpr int ESZ = 2;
+    typedef frag_t afrag_t;     // A operand (weights), as streamed from memory
+    typedef frag_t bfrag_t;     // B operand (activations), as read from LDS
+    static constexpr int ESZ = 2;       // bytes per element of an LDS row
+    static constexpr int WSZ = 2;       // bytes per element of a weight stream
     static constexpr int ID = 1;
+    static constexpr bool SPLIT = false;    // activations stored as hi + lo
     __device__ static __forceinline__ void mma(
         const frag_t& a, const frag_t& b, floatx16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -110,8 +114,12 @@ struct ElemF16 {
 struct ElemBF16 {
     typedef __bf16 lds_t;
     typedef bf16x8 frag_t;
+    typedef frag_t afrag_t;
+    typedef frag_t bfrag_t;
     static constexpr int ESZ = 2;
+    static constexpr int WSZ = 2;
     static constexpr int ID = 2;
+    static constexpr bool SPLIT = false;
     __device__ static __forceinline__ void mma(
         const frag_t& a, const frag_t& b, floatx16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -139,8 +147,12 @@ struct ElemBF16 {
 struct ElemF32 {
     typedef float lds_t;
     struct frag_t { float4 lo, hi; };
+    typedef frag_t afrag_t;
+    typedef frag_t bfrag_t;
     static constexpr int ESZ = 4;
+    static constexpr int WSZ = 4;
     static constexpr int ID = 0;
+    static constexpr bool SPLIT = false;
     __device__ static __forceinline__ void mma(
         const frag_t& a, const frag_t& b, floatx16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.x, b.lo.x, c, 0, 0, 0);
@@ -176,12 +188,18 @@ struct ElemF32 {
 struct ElemF16X3 {
     typedef _Float16 lds_t;
     struct frag_t { half8 hi, lo; };
+    typedef frag_t afrag_t;
+    typedef frag_t bfrag_t;
     static constexpr int ESZ = 4;
+    static constexpr int WSZ = 4;
     static constexpr int ID = 3;
+    static constexpr bool SPLIT = true;
     static constexpr bool BIAS_SPLIT = true;
     __device__ static __forceinline__ void mma(
         const frag_t& a, const frag_t& b, floatx16& c) {
+#if !(defined(PM_TUNING) && defined(PM_X3_TWO_MFMA))   // (timing experiment: two of the three)
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);
+#endif
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
     }
@@ -230,6 +248,43 @@ struct ElemF16X3 {
         const pm_u4 bits = {pair, pair, pair, pair};
         const half8 ones = __builtin_bit_cast(half8, bits);
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, ones, c, 0, 0, 0);
+    }
+};
+
+// f16 operands with the ACTIVATIONS split into hi + lo and the weights rounded
+// once: a k16 step is TWO v_mfma_f32_32x32x16_f16 - w x hi, w x lo - sharing one
+// (16-byte) weight fragment, so the weight stream is ElemF16's, the LDS tiles
+// are ElemF16X3's. What it keeps of the split's benefit is the part that
+// matters in the Blocks of a trained checkpoint's last stage (the activation
+// rounding: scripts/precision_emulate.py), for two thirds
+// of the MFMAs and half the weight bytes.
+struct ElemF16A2 {
+    typedef _Float16 lds_t;
+    typedef half8 afrag_t;
+    typedef ElemF16X3::frag_t bfrag_t;
+    typedef afrag_t frag_t;             // (the weight stream's unit)
+    static constexpr int ESZ = 4;
+    static constexpr int WSZ = 2;
+    static constexpr int ID = 4;
+    static constexpr bool SPLIT = true;
+    static constexpr bool BIAS_SPLIT = true;
+    __device__ static __forceinline__ void mma(
+        const afrag_t& a, const bfrag_t& b, floatx16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b.lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b.hi, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void store4_at(
+        char* rowp, int ch, float4 v) {
+        ElemF16X3::store4_at(rowp, ch, v);
+    }
+    __device__ static __forceinline__ void pack_store(
+        void* out, long long index, float v) {
+        reinterpret_cast<_Float16*>(out)[index] = (_Float16)v;
+    }
+    __device__ static __forceinline__ lds_t cvt(float v) { return (_Float16)v; }
+    __device__ static __forceinline__ void mma_bias(
+        const afrag_t& a, floatx16& c) {
+        ElemF16::mma_bias(a, c);
     }
 };
 

@@ -143,8 +143,8 @@ struct ChunkStager {
 // barrier, so its L2 latency is off the critical path of mma_taps()).
 template <class ET, int MTW, int G>
 __device__ __forceinline__ void load_a_group(
-    typename ET::frag_t (&dst)[G][MTW],
-    const typename ET::frag_t* __restrict__ wptr, const int w_mt_stride) {
+    typename ET::afrag_t (&dst)[G][MTW],
+    const typename ET::afrag_t* __restrict__ wptr, const int w_mt_stride) {
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -169,10 +169,10 @@ template <class ET, int KT, int KC, int MTW, int NTW, int G, int S,
           class Hook = NoHook, int BDO = 0>
 __device__ __forceinline__ void mma_taps(
     floatx16 (&acc)[MTW][NTW], const char* bptr, const int tap_bytes,
-    const typename ET::frag_t* __restrict__ wptr, const int w_mt_stride,
-    typename ET::frag_t (&first)[G][MTW],
-    const typename ET::frag_t* __restrict__ wnext, Hook mid = Hook()) {
-    typedef typename ET::frag_t frag_t;
+    const typename ET::afrag_t* __restrict__ wptr, const int w_mt_stride,
+    typename ET::afrag_t (&first)[G][MTW],
+    const typename ET::afrag_t* __restrict__ wnext, Hook mid = Hook()) {
+    typedef typename ET::afrag_t frag_t;
     constexpr int NS = KT * KC;
 #if defined(PM_TUNING) && defined(PM_ABLATE_MMA)   // timing experiment only: no MFMA loops
     return;
@@ -180,16 +180,17 @@ __device__ __forceinline__ void mma_taps(
     // (split-f16: fragments are twice as wide and a step is three MFMAs per
     // tile; the second B buffer is what spilled in the whole-MRF kernel, and
     // the SIMD's other wave covers the LDS round trip)
-    constexpr int BD = BDO ? BDO : (ET::ID == 3 && NTW >= 2 ? 1 : PM_BDEPTH);
+    constexpr int BD = BDO ? BDO : (ET::SPLIT && NTW >= 2 ? 1 : PM_BDEPTH);
     static_assert(NS % G == 0, "group size must divide the step count");
     static_assert(NS >= BD, "fewer steps than B buffers");
+    typedef typename ET::bfrag_t bfrag_t;
     frag_t abuf[2][G][MTW];   // A (weights): one GROUP ahead, from L2
-    frag_t bbuf[BD][NTW];     // B (activations): BD - 1 STEPS ahead, from LDS
-    auto load_b = [&](frag_t (&dst)[NTW], const int step) {
+    bfrag_t bbuf[BD][NTW];    // B (activations): BD - 1 STEPS ahead, from LDS
+    auto load_b = [&](bfrag_t (&dst)[NTW], const int step) {
         const int j = step / KC, kc = step % KC;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-            dst[nt] = *reinterpret_cast<const frag_t*>(
+            dst[nt] = *reinterpret_cast<const bfrag_t*>(
                 bptr + nt * 32 * S + j * tap_bytes + kc * 16 * ET::ESZ);
     };
 #pragma unroll
@@ -287,8 +288,8 @@ __device__ __forceinline__ void mma_taps(
 // Bias step of a packed weight stream (see the layout comment above)
 template <class ET, int MTW>
 __device__ __forceinline__ void load_bias_frags(
-    typename ET::frag_t (&bf)[MTW],
-    const typename ET::frag_t* __restrict__ wbias, const int w_mt_stride) {
+    typename ET::afrag_t (&bf)[MTW],
+    const typename ET::afrag_t* __restrict__ wbias, const int w_mt_stride) {
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) bf[mt] = wbias[mt * w_mt_stride];
 }
@@ -296,7 +297,7 @@ __device__ __forceinline__ void load_bias_frags(
 // acc = bias: the tile's first MFMA takes the constant 0 as its C operand
 template <class ET, int MTW, int NTW>
 __device__ __forceinline__ void bias_start(
-    floatx16 (&acc)[MTW][NTW], const typename ET::frag_t (&bf)[MTW]) {
+    floatx16 (&acc)[MTW][NTW], const typename ET::afrag_t (&bf)[MTW]) {
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -311,7 +312,7 @@ __device__ __forceinline__ void bias_start(
 // acc += bias (acc already holds the residual trunk)
 template <class ET, int MTW, int NTW>
 __device__ __forceinline__ void bias_add(
-    floatx16 (&acc)[MTW][NTW], const typename ET::frag_t (&bf)[MTW]) {
+    floatx16 (&acc)[MTW][NTW], const typename ET::afrag_t (&bf)[MTW]) {
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -420,7 +421,7 @@ __host__ __device__ constexpr int pair_smem_bytes(int d) {
 template <class ET, int C, int K, int WM, int WN, int NTW, int CH, int ALIAS>
 __global__ __launch_bounds__(WM * WN * 64) void conv_pair_kernel(
     PairArgs a) {
-    typedef typename ET::frag_t frag_t;
+    typedef typename ET::afrag_t frag_t;
     constexpr int NCH = C / CH;
     constexpr int KC = CH / 16;
     constexpr int MT = C / 32;
@@ -705,7 +706,7 @@ template <class ET, int KT, int KSPAN, int CH, int WM, int WN, int MTW, int NTW,
           int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
     SingleArgs a) {
-    typedef typename ET::frag_t frag_t;
+    typedef typename ET::afrag_t frag_t;
     constexpr int KC = CH / 16;
     constexpr int N1 = WN * NTW * 32;
     constexpr int NT = WM * WN * 64;
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_single_kernel(
 template <class ET, int CIN, int WM, int WN, int MTW, int NTW>
 __global__ __launch_bounds__(WM * WN * 64) void conv_upsample_kernel(
     SingleArgs a) {
-    typedef typename ET::frag_t frag_t;
+    typedef typename ET::afrag_t frag_t;
     constexpr int KT = 2, KSPAN = 3;
     constexpr int KC = CIN / 16;
     constexpr int N1 = WN * NTW * 32;
@@ -1117,7 +1118,7 @@ __device__ __forceinline__ void block3_body(
     floatx16 (&sum)[(C / 32) / WM][NTW],
     floatx16 (&xnext)[(C / 32) / WM][NTW],
     const B3Walk* wk = nullptr) {
-    typedef typename ET::frag_t frag_t;
+    typedef typename ET::afrag_t frag_t;
     constexpr int CH = C < 64 ? C : 64;    // weight-stream chunk (as packed)
     constexpr int NCH = C / CH;
     constexpr int KC = CH / 16;
@@ -1134,7 +1135,7 @@ __device__ __forceinline__ void block3_body(
     // (weight-fragment prefetch depth in k16 steps; a split-f16 step is three
     // MFMAs per tile - 192+ cycles at two tiles per wave -, so one step ahead
     // covers the L2 round trip and depth 2 spilled at C = 32 k 11)
-    constexpr int G = (ET::ESZ == 4) ? (ET::ID == 3 && NTW >= 2 ? 1 : 2) : KC;
+    constexpr int G = (ET::ESZ == 4) ? (ET::SPLIT && NTW >= 2 ? 1 : 2) : KC;
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;          // bias step of a stream
     constexpr int W_MT_STRIDE = W_BIAS + 64;
@@ -1581,7 +1582,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_kernel(MrfArgs m) {
         // (split-f16 operands: fragments are twice as wide and the kernel is
         // MFMA-bound - no registers for the hand-over, every Block reads its
         // x tile itself, out of L2)
-        constexpr int XN = ET::ID == 3 ? 0 : 1;
+        constexpr int XN = ET::SPLIT ? 0 : 1;
         floatx16 xnext[(C / 32) / WM][NTW];
         block3_body<ET, C, 11, WM, WN, NTW, 1, 2 * XN>(m.k[2], smem, sum, xnext);
         pm_block_sync();
@@ -1821,7 +1822,7 @@ template <class ET, int C, int K, int WM, int WN, int NTW>
 __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
     Block3SkewArgs p) {
     typedef SkewGeom<ET, C, K, WM, WN, NTW> GE;
-    typedef typename ET::frag_t frag_t;
+    typedef typename ET::afrag_t frag_t;
     constexpr int CH = C < 64 ? C : 64;
     constexpr int NCH = C / CH;
     constexpr int KC = CH / 16;
@@ -1834,14 +1835,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
     constexpr int QS = S / 16;
     // (split f16: weight prefetch depth 1 - depth 2 spills at k 11 and measures
     // the same; its B fragments two steps deep: -3 % at k 11, profiles/r04/ab_x3_skew.txt)
-    constexpr int G = (ET::ESZ == 4) ? (ET::ID == 3 ? 1 : 2) : KC;
+    constexpr int G = (ET::ESZ == 4) ? (ET::SPLIT ? 1 : 2) : KC;
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;
     constexpr int W_MT_STRIDE = W_BIAS + 64;
     constexpr int AUX = 16;        // sc1: served by the L2, never by this CU's L1
     // (B-fragment depth of the MFMA loops: the default rule, or - split f16,
     // where this kernel has the registers the fused whole-MRF kernel lacks - 2)
-    constexpr int PM_SKEW_BD = ET::ID == 3 ? 2 : 0;
+    constexpr int PM_SKEW_BD = ET::SPLIT ? 2 : 0;
     static_assert(NTW >= 2, "the trunk shift needs two tiles per wave");
     // (the exchange slot is 64 B x 64 rows of the receiving wave's part of t: a
     // row of its MTW x 32 channels is 64 B with 16-bit operands, 128 B with the

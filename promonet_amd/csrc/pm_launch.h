@@ -23,7 +23,7 @@
 #define PM_SKEW16_C32 0
 #endif
 constexpr bool pm_x3skew_id(int id) {
-    return id == 3 || (PM_X3SKEW_F32 && id == 0) ||
+    return id == 3 || id == 4 || (PM_X3SKEW_F32 && id == 0) ||
            (PM_SKEW16_C32 && (id == 1 || id == 2));
 }
 
@@ -160,6 +160,8 @@ template <> struct PairCfg<ElemF32, 32>  { enum { WM = 1, WN = 4, NTW = 1, CH = 
 // split f16 (hi + lo, three MFMAs per step): 4 bytes per element like fp32,
 // the same tiles
 template <int C> struct PairCfg<ElemF16X3, C> : PairCfg<ElemF32, C> {};
+// activations split, weights single f16: the same LDS tiles
+template <int C> struct PairCfg<ElemF16A2, C> : PairCfg<ElemF32, C> {};
 
 // Latency variant: when the wide tiling yields fewer workgroups than the chip
 // has CUs (single utterances: 8 tiles at C = 256 for 2 s of audio), 64-column
@@ -175,6 +177,8 @@ template <> struct PairCfgNarrow<ElemF32, 256> { enum { WM = 4, WN = 2, NTW = 1,
 template <> struct PairCfgNarrow<ElemF32, 128> { enum { WM = 4, WN = 2, NTW = 1, CH = 64, ALIAS = 0 }; };
 template <> struct PairCfgNarrow<ElemF16X3, 256> : PairCfgNarrow<ElemF32, 256> {};
 template <> struct PairCfgNarrow<ElemF16X3, 128> : PairCfgNarrow<ElemF32, 128> {};
+template <> struct PairCfgNarrow<ElemF16A2, 256> : PairCfgNarrow<ElemF32, 256> {};
+template <> struct PairCfgNarrow<ElemF16A2, 128> : PairCfgNarrow<ElemF32, 128> {};
 template <> struct PairCfgNarrow<ElemBF16, 256> : PairCfgNarrow<ElemF16, 256> {};
 template <> struct PairCfgNarrow<ElemBF16, 128> : PairCfgNarrow<ElemF16, 128> {};
 #define PM_NARROW_BELOW 150   // 3x the tiles must still fit ~2 rounds of 256 CUs
@@ -295,6 +299,7 @@ template <> struct Block3Cfg<ElemF32, 64, 3>   { enum { WM = 2, WN = 4, NTW = 2 
 template <> struct Block3Cfg<ElemF32, 64, 7>   { enum { WM = 2, WN = 4, NTW = 2 }; };
 template <> struct Block3Cfg<ElemF32, 64, 11>  { enum { WM = 2, WN = 4, NTW = 2 }; };
 template <int C, int K> struct Block3Cfg<ElemF16X3, C, K> : Block3Cfg<ElemF32, C, K> {};
+template <int C, int K> struct Block3Cfg<ElemF16A2, C, K> : Block3Cfg<ElemF32, C, K> {};
 
 // Latency variants (see PairCfgNarrow): half the waves, same per-wave tile.
 template <class ET, int C, int K> struct Block3CfgNarrow : Block3Cfg<ET, C, K> {};

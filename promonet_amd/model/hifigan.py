@@ -17,6 +17,16 @@ from promonet_amd import _lib
 from .core import attach
 
 
+def checkpoint_schedule(stages):
+    """The operand types 'checkpoint' (config.py) stands for, one per upsampling
+    stage: f16 everywhere; in the LAST stage the activations split into hi + lo
+    ('f16a2': its Blocks two MFMAs per step, its upsampler fully split), and
+    the upsampler in front of the second-to-last stage fully split as well
+    ('f16ux'). scripts/checkpoint_schedule.py measures the candidates."""
+    if stages == 1:
+        return ['f16a2']
+    return ['f16'] * (stages - 2) + ['f16ux', 'f16a2']
+
 class HiFiGAN(torch.nn.Module):
 
     def __init__(self, initial_channel, gin_channels):
@@ -145,9 +155,7 @@ class HiFiGAN(torch.nn.Module):
         # conv takes the first)
         per_stage = str(self.compute_dtype).split('+')
         if per_stage == ['checkpoint']:
-            # the trained-checkpoint mode (config.py): f16 operands, split
-            # into hi + lo in the last upsampling stage
-            per_stage = ['f16'] * (len(self.rates) - 1) + ['f16x3']
+            per_stage = checkpoint_schedule(len(self.rates))
         if len(per_stage) not in (1, len(self.rates)):
             raise ValueError(
                 f'COMPUTE_DTYPE {self.compute_dtype!r}: one operand type, or '

@@ -6,7 +6,7 @@ cd $(dirname $0)/..
 SUF=$1; shift
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-value -fno-honor-nans $*"
 mkdir -p build/obj_$SUF
-for f in pm_api pm_conv_f16 pm_conv_bf16 pm_conv_f32 pm_conv_f16x3; do
+for f in pm_api pm_conv_f16 pm_conv_bf16 pm_conv_f32 pm_conv_f16x3 pm_conv_f16a2; do
   /opt/rocm/bin/hipcc $F -c promonet_amd/csrc/$f.hip -o build/obj_$SUF/$f.o &
 done
 for f in pm_conv_f16_mrf pm_conv_bf16_mrf; do   # (Makefile: MRF_FLAGS)

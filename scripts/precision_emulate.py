@@ -39,13 +39,26 @@ def split(x, fmt):
     return hi, lo
 
 
-def conv(x, w, bias, fmt, second=False, **kw):
-    """One convolution with operand format `fmt` (None: exact fp32)."""
+def conv(x, w, bias, fmt, second=False, role=None, **kw):
+    """One convolution with operand format `fmt` (None: exact fp32).
+    `fmt` may carry a per-conv schedule: 'f16:up=x3,c1=x3,c2=a2,c1k3=a2' - the
+    split of the upsampler / the conv1s / the conv2s of the stage, optionally
+    of one kernel size only (role = ('c1', 11)); unnamed convs: one rounding."""
     op = kw.pop('op', F.conv1d)
     if fmt is None or fmt == 'fp32':
         return op(x, w, bias, **kw)
     xh, xl = split(x, fmt)
     wh, wl = split(w, fmt)
+    if ':' in fmt:
+        table = dict(item.split('=') for item in fmt.split(':')[1].split(','))
+        which, k = role
+        suffix = table.get(f'{which}k{k}', table.get(which, ''))
+        out = op(xh, wh, bias, **kw)
+        if suffix in ('a2', 'x3'):
+            out = out + op(xl, wh, None, **kw)
+        if suffix in ('w2', 'x3'):
+            out = out + op(xh, wl, None, **kw)
+        return out
     suffix = fmt[3:] if fmt.startswith('f16') else fmt[4:]
     if suffix == 'x3c2':
         suffix = 'x3' if second else ''
@@ -64,14 +77,15 @@ def conv(x, w, bias, fmt, second=False, **kw):
 def forward(features, glob, w, formats):
     _, rates, kernels = oracle.hifigan_config(w)
     x = conv(features, w['model.input_feature_conv.weight'],
-             w['model.input_feature_conv.bias'], formats[0], padding=3)
+             w['model.input_feature_conv.bias'], formats[0], role=('in', 7),
+             padding=3)
     x = x + F.conv1d(glob, w['model.input_speaker_conv.weight'],
                      w['model.input_speaker_conv.bias'])
     for i, (r, k) in enumerate(zip(rates, kernels)):
         fmt = formats[i]
         x = F.leaky_relu(x, .1)
         x = conv(x, w[f'model.model.{i}.model.1.weight'],
-                 w[f'model.model.{i}.model.1.bias'], fmt,
+                 w[f'model.model.{i}.model.1.bias'], fmt, role=('up', 0),
                  op=F.conv_transpose1d, stride=r, padding=(k - r) // 2)
         xs = None
         for j, (ks, dil) in enumerate(zip(
@@ -81,12 +95,12 @@ def forward(features, glob, w, formats):
             for n, d in enumerate(dil):
                 t = F.leaky_relu(y, .1)
                 t = conv(t, w[f'{prefix}.convs1.{n}.weight'],
-                         w[f'{prefix}.convs1.{n}.bias'], fmt,
+                         w[f'{prefix}.convs1.{n}.bias'], fmt, role=('c1', ks),
                          padding=oracle.get_padding(ks, d), dilation=d)
                 t = F.leaky_relu(t, .1)
                 t = conv(t, w[f'{prefix}.convs2.{n}.weight'],
                          w[f'{prefix}.convs2.{n}.bias'], fmt, second=True,
-                         padding=oracle.get_padding(ks, 1))
+                         role=('c2', ks), padding=oracle.get_padding(ks, 1))
                 y = y + t
             xs = y if xs is None else xs + y
         x = xs / 3
