@@ -1835,7 +1835,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
     constexpr int QS = S / 16;
     // (split f16: weight prefetch depth 1 - depth 2 spills at k 11 and measures
     // the same; its B fragments two steps deep: -3 % at k 11, profiles/r04/ab_x3_skew.txt)
-    constexpr int G = (ET::ESZ == 4) ? (ET::SPLIT ? 1 : 2) : KC;
+#ifndef PM_A2_SKEW_G
+#define PM_A2_SKEW_G 2     // (-3.7 % at k 11 over depth 1: profiles/r06/ab_a2g2.txt)
+#endif
+    constexpr int G = (ET::ESZ == 4)
+        ? (ET::SPLIT ? (ET::WSZ == 2 ? PM_A2_SKEW_G : 1) : 2) : KC;
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;
     constexpr int W_MT_STRIDE = W_BIAS + 64;
