@@ -296,8 +296,9 @@ int pm_debug_skew(int mode);
 /* Measurement aid (bench.py): a register-resident loop of v_mfma_f32_32x32x16
  * (dtype PM_F16 | PM_BF16) - `workgroups` x 4 waves x `iterations` x 16 MFMAs
  * of 32 768 FLOP each - whose HIP-event time gives the matrix pipe's SUSTAINED
- * rate on this device under its power cap. operands: >= 65 536 bytes of finite
- * values of that type; sink: 4 bytes (never written).                       */
+ * rate on this device under its power cap. operands: >= 32 768 bytes of finite
+ * values of that type; sink: 4 bytes (never written). Always available (no
+ * PROMONET_HIP_DEBUG needed): it changes no state of the library.           */
 int pm_mfma_probe(int dtype, int iterations, const void* operands,
                   float* sink, int workgroups, void* stream);
 /* Scratch the skewed whole-Block walk wants BEHIND the 3 x

@@ -1455,12 +1455,11 @@ extern "C" int pm_debug_force(int walk_nseg, int upsample_groups) {
     return PM_OK;
 }
 
-// Test hook: -1 keeps the launchers off the skewed whole-Block walk, 1 takes
-// it wherever it fits, 0 restores the default (the shapes it measured faster
-// on, when scratch was handed over).
 // Sustained-rate probe of the matrix pipe (bench.py times it with HIP events
 // on `stream`): `workgroups` x 4 waves x `iterations` x 16 MFMAs of 32 768 FLOP.
-// operands: >= 65 536 bytes of finite values of the operand type.
+// operands: >= 32 768 bytes of finite values of the operand type (2 048 uint4
+// are read). A measurement aid, not a test hook: always available, it changes
+// no state of the library.
 extern "C" int pm_mfma_probe(int dtype, int iterations, const void* operands,
                              float* sink, int workgroups, void* stream) {
     if (!operands || !sink) return fail(PM_EINVAL, "null argument");
@@ -1480,6 +1479,9 @@ extern "C" int pm_mfma_probe(int dtype, int iterations, const void* operands,
     return PM_OK;
 }
 
+// Test hook: -1 keeps the launchers off the skewed whole-Block walk, 1 takes
+// it wherever it fits, 0 restores the default (the shapes it measured faster
+// on, when scratch was handed over).
 extern "C" int pm_debug_skew(int mode) {
     if (!debug_hooks_enabled())
         return fail(PM_ESTATE, "debug hooks are disabled "

@@ -126,6 +126,30 @@ __device__ __forceinline__ void pk_cmul_each(pm_v2 (&z)[N], const pm_v2 (&w)[N])
         asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] "
             "neg_lo:[0,1,0]" : "=v"(z[i]) : "v"(z[i]), "v"(w[i]), "v"(t[i]));
 }
+// (a.x + a.y, a.x - a.y)
+__device__ __forceinline__ pm_v2 pk_sumdiff(pm_v2 a) {
+    pm_v2 d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]"
+        : "=v"(d) : "v"(a));
+    return d;
+}
+// Sum of v over the 64 lanes of the wave, returned wave-uniform: six DPP adds
+// (quad swaps, the two row mirrors, then the row broadcasts that gfx9 keeps:
+// row_bcast:15 / :31 leave the total in lane 63) and one v_readlane.
+__device__ __forceinline__ float pm_wave_sum(float v) {
+#define PM_DPP_ADD(ctrl, rows)                                                \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(               \
+        0, __builtin_bit_cast(int, v), ctrl, rows, 0xf, true))
+    PM_DPP_ADD(0xB1, 0xf);      // quad_perm:[1,0,3,2]
+    PM_DPP_ADD(0x4E, 0xf);      // quad_perm:[2,3,0,1]
+    PM_DPP_ADD(0x141, 0xf);     // row_half_mirror
+    PM_DPP_ADD(0x140, 0xf);     // row_mirror
+    PM_DPP_ADD(0x142, 0xa);     // row_bcast:15 into rows 1 and 3
+    PM_DPP_ADD(0x143, 0xc);     // row_bcast:31 into rows 2 and 3
+#undef PM_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+        __builtin_bit_cast(int, v), 63));
+}
 // |a|^2
 __device__ __forceinline__ float pk_norm(pm_v2 a) {
     const pm_v2 q = a * a;
@@ -223,6 +247,11 @@ __global__ __launch_bounds__(NW * 64, NW * FPW == 32 ? 2 : (EPI == 1 || EPI == 4
 void pm_stft_fft_kernel(FftArgs a) {
     constexpr int FR = NW * FPW;
     constexpr int NT = NW * 64;
+#ifdef PM_FFT_NO_DIRECT_DC           // (A/B builds)
+    constexpr bool DIRECT_DC = false;
+#else
+    constexpr bool DIRECT_DC = EPI == 2 || EPI == 3 || EPI == 5;
+#endif
     constexpr int WS = 576;          // complex slots per wave (8 x 72)
     constexpr int OS = FR + 1;       // staging row pitch (floats)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -361,6 +390,28 @@ void pm_stft_fft_kernel(FftArgs a) {
             asm volatile("" : "+v"(glane));
             pm_fft_load_frame(raw, an, min(tn, T - 1), N, glane);
         }
+        // Bins 0 and 512 directly (the dB epilogues): X[0] = sum w x, X[512] =
+        // sum (-1)^n w x. Out of the transform they are Re Z[0] +- Im Z[0] - a
+        // difference of two 512-term sums that carries the whole frame's
+        // rounding noise (8e-8 of its amplitude), which a bin 70 dB under its
+        // frame shows as millidecibels of loudness. Here the sum and the
+        // difference of every (even, odd) sample pair are formed FIRST - the
+        // cancellation happens between two neighbouring samples, where it is
+        // all but exact - and only then added up: 8 + 7 packed instructions
+        // and two 6-step wave sums a frame. (The magnitude / log-mel
+        // epilogues add 1e-6 under a square root and keep the transform's.)
+        [[maybe_unused]] float x_dc = 0.f, x_ny = 0.f;
+        if constexpr (DIRECT_DC) {
+            pm_v2 sd[8];
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) sd[n2] = pk_sumdiff(z[n2]);
+#pragma unroll
+            for (int h = 4; h > 0; h >>= 1)
+#pragma unroll
+                for (int n2 = 0; n2 < h; ++n2) sd[n2] = pk_add(sd[n2], sd[n2 + h]);
+            x_dc = pm_wave_sum(sd[0].x);
+            x_ny = pm_wave_sum(sd[0].y);
+        }
         pm_radix8(z);
         pk_cmul_each<1>(z, twa);
         pm_wave_lds_sync();                 // (previous frame's reads of wk)
@@ -421,10 +472,16 @@ void pm_stft_fft_kernel(FftArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = lane + 64 * j;
-                bin_out(pk_norm(pk_add(e2[j], dd[j])), k,
-                        (EPI == 3 || EPI == 5) ? wlo[j] : 0.f, j);
-                bin_out(pk_norm(pk_sub(e2[j], dd[j])), 512 - k,
-                        (EPI == 3 || EPI == 5) ? whi[j] : 0.f, 7 - j);
+                float plo = pk_norm(pk_add(e2[j], dd[j]));
+                float phi = pk_norm(pk_sub(e2[j], dd[j]));
+                if (DIRECT_DC && j == 0) {
+                    // (lane 0: bins 0 and 512, from the direct sums)
+                    plo = lane == 0 ? 4.f * x_dc * x_dc : plo;
+                    phi = lane == 0 ? 4.f * x_ny * x_ny : phi;
+                }
+                bin_out(plo, k, (EPI == 3 || EPI == 5) ? wlo[j] : 0.f, j);
+                bin_out(phi, 512 - k, (EPI == 3 || EPI == 5) ? whi[j] : 0.f,
+                        7 - j);
             }
         }
         {

@@ -32,8 +32,13 @@ _STATE = {
 
 
 def backend():
-    """Backend of the data plane: 'nccl' (= RCCL), 'gloo', or None."""
-    return _STATE['backend'] if dist.is_initialized() else None
+    """Backend of the data plane: 'nccl' (= RCCL), 'gloo', or None. A process
+    group the CALLER created (init() left it alone, _STATE is empty) answers
+    for itself: a gloo group must get its device tensors staged through the
+    host, an nccl group keeps the gather overlap."""
+    if not dist.is_initialized():
+        return None
+    return _STATE['backend'] or dist.get_backend(_STATE['group'])
 
 
 def data_group():

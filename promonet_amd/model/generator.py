@@ -302,8 +302,14 @@ class Generator(torch.nn.Module):
         one may be re-allocated by a later, larger forward, and a captured
         kernel keeps the pointer it was recorded with."""
         vocoder = self.model
-        with torch.no_grad(), torch.cuda.device(x.device):
-            static = x.clone()
+        # (inference mode OFF for the capture: the static input is written in
+        # place on every replay, by callers inside AND outside
+        # torch.inference_mode() - an inference tensor would refuse the second
+        # kind - and the captured output is cloned by both)
+        with torch.inference_mode(False), torch.no_grad(), \
+                torch.cuda.device(x.device):
+            static = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            static.copy_(x)
             self.packed_inference(static)
             shared = vocoder._workspace
             vocoder._workspace = None

@@ -227,11 +227,14 @@ def from_files_to_files_batched(
     reference's one-utterance loop (synthesize/core.py:158-201). Same files,
     same audio as the sequential path. SURVEY.md 8(f) item 2.
 
-    `num_workers` CPU processes (opt-in; default 0: everything in this
-    process, so that a caller script needs no `if __name__ == '__main__':`
-    guard; `promonet_amd.NUM_WORKERS` = the size of the pools the reference
-    forks for its file-level preprocessing, defaults.py:387, is what the CLI
-    passes) unpickle the feature files, pad the batches and write the wav
+    `num_workers` CPU processes (OPT-IN only - nothing in this package passes
+    it, the CLI mirrors the reference's flags and its sequential loop; default
+    0: everything in this process, so that a caller script needs no
+    `if __name__ == '__main__':` guard; a natural value is
+    `promonet_amd.NUM_WORKERS`, the size of the pools the reference forks for
+    its file-level preprocessing, defaults.py:387; the `configure()` overrides
+    travel to the workers as `Pool` initargs and therefore have to pickle)
+    unpickle the feature files, pad the batches and write the wav
     files while the GPU synthesises: the serial loop spends three quarters of
     its time in `torch.load` and the wav writer. The pool is started on first
     use and kept (`shutdown_workers()` ends it; it is keyed on the

@@ -189,3 +189,40 @@ def test_backend_is_decided_from_the_devices():
     # CPU ranks (no GPU): gloo, identical 'cpu' identities are not "shared"
     assert distributed.decide_backend(ranks(['cpu'] * 4), 4, 0, False) == (
         'gloo', {}, None)
+
+
+def caller_group_worker(rank, world, port, results):
+    """The process group exists before distributed.init() is ever called (a
+    host application that owns torch.distributed): the data plane must take
+    ITS backend, not 'nothing initialised' (ADVICE r05)."""
+    os.environ.update(
+        RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+        MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    assert distributed.backend() == 'gloo'
+    assert not distributed._host_staged(torch.zeros(1))   # (CPU tensors: nothing to stage)
+    model = torch.nn.Linear(3, 2)
+    torch.manual_seed(rank)
+    with torch.no_grad():
+        model.weight.copy_(torch.rand(2, 3))
+    distributed.broadcast_model(model)
+    torch.manual_seed(0)
+    assert torch.equal(model.weight, torch.rand(2, 3))
+    results.put(rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_caller_created_group_is_recognised():
+    context = mp.get_context('spawn')
+    results = context.Queue()
+    port = free_port()
+    processes = [
+        context.Process(target=caller_group_worker, args=(rank, 2, port, results))
+        for rank in range(2)]
+    for process in processes:
+        process.start()
+    for process in processes:
+        process.join(120)
+        assert process.exitcode == 0
+    assert sorted(results.get(timeout=5) for _ in range(2)) == [0, 1]

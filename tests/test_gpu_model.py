@@ -895,6 +895,19 @@ def test_packed_inference_graph(device, default_state, dtype):
         assert torch.equal(
             model.packed_inference(pair, graph=True),
             model.packed_inference(pair))
+    # a shape captured INSIDE inference mode replays outside it and the other
+    # way round (the static input of a graph is updated in place by both)
+    inside, outside = packed(1, 24), packed(1, 40)
+    with torch.inference_mode():
+        first_inside = model.packed_inference(inside, graph=True)
+        want_outside = model.packed_inference(outside)
+    assert torch.equal(
+        model.packed_inference(inside.clone(), graph=True), first_inside)
+    first_outside = model.packed_inference(outside.clone(), graph=True)
+    with torch.inference_mode():
+        assert torch.equal(
+            model.packed_inference(outside, graph=True), first_outside)
+    assert torch.equal(first_outside, want_outside)
     # a much larger eager forward re-allocates the module's shared workspace
     chunk = packed(1, 32)
     before = model.packed_inference(chunk, graph=True)
