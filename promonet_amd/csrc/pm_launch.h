@@ -22,8 +22,11 @@
 #ifndef PM_SKEW16_C32
 #define PM_SKEW16_C32 0
 #endif
+#ifndef PM_A2_SKEW
+#define PM_A2_SKEW 1
+#endif
 constexpr bool pm_x3skew_id(int id) {
-    return id == 3 || id == 4 || (PM_X3SKEW_F32 && id == 0) ||
+    return id == 3 || (PM_A2_SKEW && id == 4) || (PM_X3SKEW_F32 && id == 0) ||
            (PM_SKEW16_C32 && (id == 1 || id == 2));
 }
 

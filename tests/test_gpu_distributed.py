@@ -128,6 +128,46 @@ def test_bench_self_launches_two_ranks(device):
     assert multi['hang_watchdog_seconds'] == 120
 
 
+def test_bench_eight_folded_ranks_real_engine(device):
+    """`python bench.py --gpus 8` on the 1-GPU box: 8 ranks fold onto cuda:0
+    and run the REAL engine (batch 4 x 2 s per rank) - eight engines and
+    workspaces on one device, eight flat weight broadcasts into packed
+    engines (`invalidate_engines`), the sustained-loop step count broadcast
+    from rank 0, the fixed-size all-gather through `GatherPipeline` - over
+    the gloo data plane the device-identity exchange falls back to, loudly.
+    What the 8-GPU job adds to this is RCCL and seven more devices. NOT a
+    scaling measurement (no N > 1 curve has been measured: DESIGN.md 7)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR',
+                        'MASTER_PORT', 'LOCAL_WORLD_SIZE')}
+    done = subprocess.run(
+        [sys.executable, str(root / 'bench.py'), '--gpus', '8', '--steps', '2',
+         '--warmup', '1', '--batch', '4', '--seconds', '2', '--sustain', '0.2',
+         '--no-cpu-baseline'],
+        capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [l for l in done.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    result = json.loads(lines[0])
+    assert result['n_gpus'] == 8 and result['world_size'] == 8
+    assert result['value'] > 0 and result['scaling'] == 'weak'
+    multi = result['multi_gpu']
+    assert multi['world_size_reported_by_backend'] == 8
+    assert len(multi['rank_ms_per_step']) == 8
+    assert len(multi['devices']) == 8
+    assert len({entry['id'] for entry in multi['devices']}) == 1   # one GPU
+    assert multi['backend'] == 'gloo' and multi['gloo_fallback']
+    assert 'gloo' in done.stderr           # (the fallback is announced)
+    assert multi['gathered_bytes_per_rank_per_step'] == 8 * 4 * 172 * 256 * 4
+    assert multi['compute_ms_per_step'] > 0
+    assert multi['gather_alone_ms_per_step'] > 0
+
+
 def test_bench_fails_fast_on_a_collective_hang(device):
     """A rank that never reaches a collective must fail the job quickly (rc != 0
     well inside the driver's patience), not hang it: rank 1 is made to stall
