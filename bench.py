@@ -334,6 +334,10 @@ def kernel_label(name):
         return 'convT_c128_r2'
     if re.search(r'conv_single_kernel<\w+,2,3,64,2,2,1,\d,0>', name):
         return 'convT_c64_r2'
+    if 'pm_fargan_cluster_kernel' in name:
+        return 'fargan_cluster'
+    if 'pm_fargan_cond_kernel' in name:
+        return 'fargan_cond'
     return None
 
 
@@ -1051,6 +1055,26 @@ def main():
             result['roofline'] = fargan_roofline(
                 promonet_amd.FARGAN_WEIGHT_DTYPE, args.batch, frames,
                 sum(times) / len(times), per_gpu)
+            if not args.no_traffic and world == 1:
+                # HBM bytes the cluster kernel really moved (rocprofv3 PMC,
+                # two passes over one forward of this command)
+                table, source = measure_traffic(args, timeout=300.)
+                if table and 'fargan_cluster' in table:
+                    result['roofline']['traffic'] = table['fargan_cluster']
+                    result['roofline']['traffic_source'] = source
+                    result['roofline']['traffic_all_kernels'] = table
+                    result['roofline']['traffic_note'] = (
+                        'memory-side requests of the 6 agent-scope exchanges '
+                        'per step (write-through granule stores and polling '
+                        'loads that bypass the L2 by construction), ~24 MB a '
+                        'step: the same for fp32 and mixed weight storage '
+                        '(profiles/r06/fargan), i.e. not weight re-reads - '
+                        'those stay under the L2 (an eighth of the weights '
+                        'per XCD)')
+                else:
+                    result['roofline']['traffic_source'] = \
+                        f'not measured: {source}'
+
         elif stand_in:
             result['stand_in'] = True
             result['roofline'] = None
