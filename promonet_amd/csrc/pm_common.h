@@ -203,13 +203,16 @@ struct ElemF16X3 {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
     }
-    // hi = rn(v) saturated at BOTH ends of the f16 range, lo = rn(v - hi),
-    // saturated too: |v| beyond 65504 becomes +-(65504 + 65504) at most, never
-    // an infinity (-inf x a zero-padded weight would be NaN in the MFMA sum).
-    // Two more v_pk_max_f16 per four values in a kernel that issues three
-    // MFMAs per step.
+    // hi = rn(v'), lo = rn(v' - hi) with v' = v clamped to the f16 range IN
+    // FP32 (one v_med3_f32 a value): |v| beyond 65504 becomes +-65504 with a
+    // zero lo part, never an infinity (-inf x a zero-padded weight would be NaN
+    // in the MFMA sum), and neither part needs a clamp of its own (round 5
+    // clamped both in f16: 8 packed min / max per four values; v' - hi is at
+    // most half an ulp of hi). The remainder is ONE v_fma_mix_f32 a value -
+    // the f16 hi part is an operand as it is, not converted back first.
     __device__ static __forceinline__ void split4(
         float4 v, half4& hi, half4& lo) {
+#ifdef PM_SPLIT_R05         // (A/B builds: round 5's form)
         const pm_f4 w = {v.x, v.y, v.z, v.w};
         const _Float16 big = (_Float16)65504.f;
         const half4 top = {big, big, big, big};
@@ -219,6 +222,28 @@ struct ElemF16X3 {
         const pm_f4 rest = w - __builtin_convertvector(hi, pm_f4);
         lo = __builtin_elementwise_max(__builtin_elementwise_min(
             __builtin_convertvector(rest, half4), top), bottom);
+#else
+        const float w[4] = {
+            __builtin_fminf(__builtin_fmaxf(v.x, -65504.f), 65504.f),
+            __builtin_fminf(__builtin_fmaxf(v.y, -65504.f), 65504.f),
+            __builtin_fminf(__builtin_fmaxf(v.z, -65504.f), 65504.f),
+            __builtin_fminf(__builtin_fmaxf(v.w, -65504.f), 65504.f)};
+        const pm_f4 wv = {w[0], w[1], w[2], w[3]};
+        hi = __builtin_convertvector(wv, half4);
+        // (inline asm: written as fmaf((float)hi, -1, w) hipcc folds the
+        // product away and converts hi back with v_cvt_f32_f16 + v_sub_f32)
+        const uint2 hp = __builtin_bit_cast(uint2, hi);
+        pm_f4 rest;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]"
+            : "=v"(rest[0]) : "v"(hp.x), "v"(w[0]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=v"(rest[1]) : "v"(hp.x), "v"(w[1]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]"
+            : "=v"(rest[2]) : "v"(hp.y), "v"(w[2]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=v"(rest[3]) : "v"(hp.y), "v"(w[3]));
+        lo = __builtin_convertvector(rest, half4);
+#endif
     }
     // channels ch .. ch + 3 of an LDS row: the 8-channel group g = ch / 8 is 32
     // bytes, hi parts first; ch % 8 selects the half of both parts

@@ -16,8 +16,14 @@ device = torch.device('cuda:0')
 lib = _lib.lib()
 NAMES = ('stage', 'conv1', 'epi1', 'barrier1', 'conv2', 'epi2', 'drain',
          'barrier2', 'store')
-for channels, length, k in ((128, 55104, 11), (128, 55104, 7), (128, 55104, 3),
-                            (64, 110208, 11), (64, 110208, 7)):
+# usage: timeline_skew.py [dtype [channels length k ...]] (default: the bf16 shapes)
+DTYPE = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+SHAPES = ((128, 55104, 11), (128, 55104, 7), (128, 55104, 3),
+          (64, 110208, 11), (64, 110208, 7))
+if len(sys.argv) > 2:
+    flat = [int(v) for v in sys.argv[2:]]
+    SHAPES = tuple(zip(flat[0::3], flat[1::3], flat[2::3]))
+for channels, length, k in SHAPES:
     batch = 32
     x = torch.randn(batch, length, channels, device=device)
     out = torch.zeros_like(x)
@@ -33,7 +39,7 @@ for channels, length, k in ((128, 55104, 11), (128, 55104, 7), (128, 55104, 3),
 
     def run():
         _lib.check(lib.pm_block_cl(
-            _lib.PM_BF16, _lib.ptr(x), _lib.ptr(out), w1, b1, w2, b2, dil, 3,
+            _lib.DTYPES[DTYPE], _lib.ptr(x), _lib.ptr(out), w1, b1, w2, b2, dil, 3,
             batch, length, channels, k, 2, 1. / 3, ws.data_ptr(), ws.numel(),
             _lib.stream()))
 
