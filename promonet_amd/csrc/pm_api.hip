@@ -807,7 +807,7 @@ static int forward_impl(
         const bool x3_skew = pm_x3skew_id(st.dtype) && st.cout_pad == 32 &&
             p.scratch && pm_device_cus() > 0 &&
             (L / 512) / std::max(1, pm_device_cus() / B) >= 4;
-        if (fusion_level() >= 2 && !x3_skew && h->cfg.num_resblocks == 3 &&
+        if (fusion_level() >= 2 && h->cfg.num_resblocks == 3 &&
             h->cfg.num_dilations <= 3 && st.cout_pad <= 64 &&
             h->cfg.resblock_kernel_sizes[0] == 3 &&
             h->cfg.resblock_kernel_sizes[1] == 7 &&
@@ -827,6 +827,12 @@ static int forward_impl(
                 }
                 a.B = B; a.L = L; a.mode = j == 0 ? 1 : 2; a.scale = scale;
                 a.lengths = lengths; a.len_scale = rate;
+                // (4-byte operand layouts on a long batch: the skewed
+                // whole-MRF walk, or Block by Block on the skewed walk - never
+                // the two-sided tiling of the fused launch, pm_launch.h)
+                a.scratch = p.scratch ? base + p.off_scratch : nullptr;
+                a.scratch_bytes = p.scratch;
+                a.skew_only = x3_skew ? 1 : 0;
             }
             char label[64];
             snprintf(label, sizeof(label), "mrf_c%d", st.cout);
@@ -1300,6 +1306,13 @@ extern "C" int pm_mrf_cl(
             a.w1[n] = p1; a.w2[n] = p2; a.dil[n] = dilations[n];
         }
     }
+    // (what the caller hands over beyond the packed weights serves the skewed
+    // whole-MRF walk of the 4-byte operand layouts: pm_walk_scratch_bytes)
+    if (ws_bytes > 3 * (size_t)niter * per)
+        for (int j = 0; j < 3; ++j) {
+            blocks[j].scratch = (char*)ws + 3 * (size_t)niter * per;
+            blocks[j].scratch_bytes = ws_bytes - 3 * (size_t)niter * per;
+        }
     hipError_t e = launch_mrf(dtype, Cp, blocks, s);
     if (e == hipErrorNotSupported)
         return fail(PM_EINVAL, "no whole-MRF kernel for this shape");

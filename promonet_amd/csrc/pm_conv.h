@@ -33,6 +33,8 @@
 // Workgroup barriers fence LDS only (pm_block_sync), so global loads stay in
 // flight across them.
 #pragma once
+#include <type_traits>
+
 #include "pm_common.h"
 
 // ---------------------------------------------------------------------------
@@ -1066,6 +1068,9 @@ struct Block3Args {
     void* act16;
     int act16_type;
     int* act16_done;
+    // pm_launch_mrf: take the skewed whole-MRF walk or nothing
+    // (hipErrorNotSupported) - the caller's fallback is Block by Block
+    int skew_only;
     PM_TIMELINE_FIELD    // debug stamps (tuning builds)
 };
 
@@ -2353,4 +2358,490 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
     if (a.timeline && threadIdx.x == 0)
         for (int i = 0; i < 10; ++i) a.timeline[(size_t)blockIdx.x * 16 + i] = ph[i];
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// The whole MRF of a stage (Blocks k 11, 7, 3 back to back) on the skewed walk:
+// conv_block3_skew_kernel's step, three times per window, with the sum of the
+// Blocks in registers. Against three skewed Block launches (what the 4-byte
+// operand layouts - split f16, exact fp32 - run at C = 32) a step reads x from
+// HBM once instead of three times (the second and third Block re-request the
+// tile the first one just pulled through the L2, under the previous Block's
+// last conv2), and `out` is written once instead of being written, then read
+// and written twice more: 1.8 GB of traffic per launch instead of 7.2, two
+// HBM round trips and two store phases a step less. Every Block keeps its own
+// carries and wrap slots in its own third of the workgroup's scratch; the LDS
+// holds one Block's two operand tiles at a time (sized for k 11). All three
+// Blocks run iteration i on the window [c0 - 32 i, ...), so their outputs
+// cover the same columns and add up in the accumulator layout.
+// Same arithmetic per column as the Block-by-Block launches except the order
+// of the final sum ((B11 + B7 + B3) / 3 with ONE scaling, as the whole-MRF
+// walk of the 16-bit types does).
+// ---------------------------------------------------------------------------
+struct MrfSkewArgs {
+    const float* x;
+    float* out;
+    const void* w1[3][3];   // [Block k 3 / 7 / 11][iteration]
+    const void* w2[3][3];
+    int dil[3][3];
+    int B, L, halo;         // halo: the k 11 Block's (the segments' warm-up)
+    float scale;
+    const int* lengths;
+    int len_scale;
+    int nseg;               // segments per utterance
+    int wg_scratch;         // bytes of scratch per workgroup
+    char* scratch;
+};
+
+template <class ET, int C, int WM, int WN, int NTW>
+struct MrfSkewGeom {
+    typedef SkewGeom<ET, C, 11, WM, WN, NTW> G11;
+    static constexpr int BLOCK_SCRATCH = G11::SCRATCH;    // (the largest)
+    static constexpr int SCRATCH = 3 * BLOCK_SCRATCH;
+    static constexpr int SMEM = G11::SMEM;
+};
+
+template <class ET, int C, int WM, int WN, int NTW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
+    MrfSkewArgs p) {
+    typedef MrfSkewGeom<ET, C, WM, WN, NTW> MG;
+    typedef typename ET::afrag_t frag_t;
+    constexpr int CH = C < 64 ? C : 64;
+    constexpr int NCH = C / CH;
+    constexpr int KC = CH / 16;
+    constexpr int MTW = (C / 32) / WM;
+    constexpr int NC = WN * NTW * 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int S = C * ET::ESZ + 16;
+    constexpr int QS = S / 16;
+    constexpr int G = (ET::ESZ == 4)
+        ? (ET::SPLIT ? (ET::WSZ == 2 ? PM_A2_SKEW_G : 1) : 2) : KC;
+    constexpr int AUX = 16;        // sc1: served by the L2, never by this CU's L1
+    constexpr int PM_SKEW_BD = ET::SPLIT ? 2 : 0;
+    constexpr int TB = MTW * 4096;
+    constexpr int Q = C / 4;
+    constexpr int SIT = (32 * Q + NT - 1) / NT;          // the x strip (fp32)
+    constexpr int CIN11 = ((32 + 4 * 5) * QS + NT - 1) / NT;
+    constexpr int PRE = CIN11 > SIT ? CIN11 : SIT;
+    static_assert(NTW >= 2, "the trunk shift needs two tiles per wave");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* abuf = smem;
+
+    const int H = p.halo;
+    const int b = blockIdx.x / p.nseg, seg = blockIdx.x % p.nseg;
+    const int L = p.lengths ? min(p.lengths[b] * p.len_scale, p.L) : p.L;
+    const int per = (((L + p.nseg - 1) / p.nseg) + 31) & ~31;
+    const int s0 = seg * per;
+    const int e0 = min(L, s0 + per);
+    if (s0 >= e0) return;
+    const MrfSkewArgs __attribute__((address_space(4)))* karg =
+        (const MrfSkewArgs __attribute__((address_space(4)))*)
+            __builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int skew = 64;            // 32 (niter - 1), niter == 3
+
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.scratch + (size_t)blockIdx.x * p.wg_scratch, 0, MG::SCRATCH,
+        0x00020000);
+    const float* __restrict__ xb = p.x + (size_t)b * p.L * C;
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m_first = wm * MTW * 32;
+    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    auto fresh_tid = []() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    auto col_offset = [&](int t) {
+        return (wn * NTW * 32 + (t & 31)) * S + ((t >> 5) & 1) * 8 * ET::ESZ;
+    };
+
+    floatx16 trunk[MTW][NTW];
+    floatx16 acc[MTW][NTW];
+    floatx16 sum[MTW][NTW];
+    frag_t bf[MTW];
+    frag_t afirst[G][MTW];
+
+    auto rows_out = [&](int tid, const char* src, int rows, unsigned soff) {
+        const int n = rows * QS;
+        for (int i = tid; i < n; i += NT) {
+            const float4 v = reinterpret_cast<const float4*>(src)[i];
+            const pm_u4 u = {__float_as_uint(v.x), __float_as_uint(v.y),
+                             __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u, srsrc, soff + (unsigned)i * 16, 0, 0);
+        }
+    };
+    auto rows_request = [&](int tid, auto& r, int rows, unsigned soff,
+                            unsigned dead) {
+        constexpr int N = sizeof(r) / sizeof(r[0]);
+#pragma unroll
+        for (int it = 0; it < N; ++it) {
+            const int i = tid + it * NT;
+            r[it] = __builtin_amdgcn_raw_buffer_load_b128(
+                srsrc, (i < rows * QS ? soff + (unsigned)i * 16 : 0x40000000u) + dead,
+                0, AUX);
+        }
+    };
+    auto rows_in = [&](int tid, char* dst, const auto& r, int rows) {
+        constexpr int N = sizeof(r) / sizeof(r[0]);
+#pragma unroll
+        for (int it = 0; it < N; ++it) {
+            const int i = tid + it * NT;
+            if (i < rows * QS)
+                reinterpret_cast<pm_u4*>(dst)[i] = r[it];
+        }
+    };
+    auto strip_request = [&](int tid, pm_u4 (&r)[PRE], int c_first) {
+        const int lo = max(c_first, 0);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xb) + (size_t)lo * C, 0,
+            max(min(L, c_first + 32) - lo, 0) * C * 4, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int idx = tid + it * NT;
+            r[it] = __builtin_amdgcn_raw_buffer_load_b128(
+                rsrc, (unsigned)(((c_first - lo) * C + idx * 4) * 4), 0, 0);
+        }
+    };
+    pm_u4 pre[PRE];
+    int left = 0, par = 0;
+
+    // One Block (kernel size KV::value) on the window of this step. POS: 0 the
+    // first Block of the step (x and the strip come from the previous STEP's
+    // requests, or are loaded here on a segment's first step), 1 the middle
+    // one, 2 the last (requests the next step's x; adds up and stores).
+    auto block_step = [&](auto kv, auto posv, const int c0) {
+        constexpr int K = decltype(kv)::value;
+        constexpr int POS = decltype(posv)::value;
+        constexpr int J = K == 3 ? 0 : K == 7 ? 1 : 2;     // row of the weight arrays
+        typedef SkewGeom<ET, C, K, WM, WN, NTW> GE;
+        constexpr int H2 = GE::H2;
+        constexpr int AL = GE::AL;
+        constexpr int CIN = (GE::CA * QS + NT - 1) / NT;
+        constexpr int TIN = (2 * H2 * QS + NT - 1) / NT;
+        constexpr int W_CHUNK = K * KC * 64;
+        constexpr int W_BIAS = NCH * W_CHUNK;
+        constexpr int W_MT_STRIDE = W_BIAS + 64;
+        constexpr unsigned SB = (unsigned)(POS * MG::BLOCK_SCRATCH);
+        char* tbuf = smem + GE::RA * S;
+        auto stream_of = [&](const void* w, int t) {
+            return reinterpret_cast<const frag_t*>(w) +
+                   (size_t)(wm * MTW) * W_MT_STRIDE + (t & 63);
+        };
+        const unsigned dead = left ? 0u : 0x40000000u;
+        const bool have_x = POS > 0 || left;
+        // (the LDS is laid out per kernel size: the previous Block's last
+        // conv2 may still be reading rows this one's staging writes)
+        pm_block_sync();
+        {
+            const frag_t* w1 = stream_of(karg->w1[J][0], fresh_tid());
+            load_bias_frags<ET, MTW>(bf, w1 + W_BIAS, W_MT_STRIDE);
+            load_a_group<ET, MTW, G>(afirst, w1, W_MT_STRIDE);
+        }
+        // ---- trunk <- x on [c0, c0 + NC), a_0 = lrelu(x) on [c0, c0 + NC + 32)
+        {
+            const int tid = fresh_tid();
+            const int ln = tid & 31, lh = (tid >> 5) & 1;
+            const int x_lo = max(c0, 0);
+            const __amdgpu_buffer_rsrc_t xrsrc =
+                __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(xb) + (size_t)x_lo * C, 0,
+                    max(min(L, c0 + NC + 32) - x_lo, 0) * C * 4, 0x00020000);
+            if (!have_x) strip_request(tid, pre, c0 + NC);
+            if (have_x) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) trunk[mt][nt] = acc[mt][nt];
+            } else {
+                const unsigned voff0 = (unsigned)(
+                    ((c0 - x_lo + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const unsigned voff =
+                            voff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const pm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                xrsrc, voff + g4 * 32, 0, 0);
+                            trunk[mt][nt][4 * g4 + 0] = __uint_as_float(v.x);
+                            trunk[mt][nt][4 * g4 + 1] = __uint_as_float(v.y);
+                            trunk[mt][nt][4 * g4 + 2] = __uint_as_float(v.z);
+                            trunk[mt][nt][4 * g4 + 3] = __uint_as_float(v.w);
+                        }
+                    }
+            }
+            const int d0 = karg->dil[J][0];
+            pm_u4 cin[CIN] = {};
+            if (d0 > 1)
+                rows_request(tid, cin, H2 * (d0 - 1), SB + GE::OFF_AC, dead);
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int col = (wn * NTW + nt) * 32 + ln;
+                    store_tile_lrelu_impl<ET, false>(
+                        abuf + (AL + col) * S, m_first + mt * 32, trunk[mt][nt],
+                        false, lh);
+                }
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) {
+                const int idx = tid + it * NT;
+                const int r = idx / Q, q = idx % Q;
+                if (idx < 32 * Q)
+                    ET::store4_at(abuf + (AL + NC + r) * S, q * 4,
+                                  pm_lrelu4(make_float4(
+                                   __uint_as_float(pre[it].x),
+                                   __uint_as_float(pre[it].y),
+                                   __uint_as_float(pre[it].z),
+                                   __uint_as_float(pre[it].w))));
+            }
+            if (d0 > 1)
+                rows_in(tid, abuf + (AL + H2 - H2 * d0) * S, cin, H2 * (d0 - 1));
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the Block kernel
+        pm_block_sync();
+
+#pragma unroll 1
+        for (int it = 0; it < 3; ++it) {
+            const int d = karg->dil[J][it];
+            const int o = c0 - 32 * it;
+            const bool more = it + 1 < 3;
+
+            bias_start<ET, MTW, NTW>(acc, bf);
+            pm_u4 tcin[TIN];
+            {
+                const int t1 = fresh_tid();
+                rows_request(t1, tcin, 2 * H2,
+                             SB + GE::OFF_TC + it * 2 * H2 * S, dead);
+                const frag_t* w1 = stream_of(karg->w1[J][it], t1);
+                const frag_t* w2 = stream_of(karg->w2[J][it], t1);
+                const int col_off = col_offset(t1);
+#pragma unroll 1
+                for (int c = 0; c < NCH; ++c)
+                    mma_taps<ET, K, KC, MTW, NTW, G, S, NoHook, PM_SKEW_BD>(
+                        acc, abuf + (AL + H2 - H2 * d) * S + col_off + c * CH * ET::ESZ,
+                        d * S, w1 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
+                        c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
+            }
+            const int tid = fresh_tid();
+            const int ln = tid & 31, lh = (tid >> 5) & 1;
+            load_bias_frags<ET, MTW>(
+                bf, stream_of(karg->w2[J][it], tid) + W_BIAS, W_MT_STRIDE);
+            {
+                const int rows = (it ? 32 : 0) + H2 * (d - 1);
+                rows_out(tid, abuf + (AL + NC + H2 - H2 * d) * S, rows,
+                         SB + GE::OFF_AC + it * GE::CA * S);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int col_first = (wn * NTW + nt) * 32;
+                    store_tile_lrelu<ET>(
+                        tbuf + (2 * H2 + col_first + ln) * S, m_first + mt * 32,
+                        acc[mt][nt], o + H2 + col_first, L, ln, lh);
+                    // x for the NEXT Block of this step (the same window) or,
+                    // from the last Block, for the next step - into the dead
+                    // conv1 accumulators, under the last conv2
+                    if (!more) {
+                        const int cn = POS == 2 ? c0 + NC : c0;
+                        const int lo = max(cn, 0);
+                        const bool wanted = POS < 2 || cn - skew < e0;
+                        const __amdgpu_buffer_rsrc_t nrsrc =
+                            __builtin_amdgcn_make_buffer_rsrc(
+                                const_cast<float*>(xb) + (size_t)lo * C, 0,
+                                (wanted ? max(min(L, cn + NC) - lo, 0) : 0) *
+                                    C * 4, 0x00020000);
+                        const unsigned voff = (unsigned)(
+                            ((cn - lo + col_first + ln) * C + m_first +
+                             mt * 32 + 4 * lh) * 4);
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const pm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                nrsrc, voff + g4 * 32, 0, 0);
+                            acc[mt][nt][4 * g4 + 0] = __uint_as_float(v.x);
+                            acc[mt][nt][4 * g4 + 1] = __uint_as_float(v.y);
+                            acc[mt][nt][4 * g4 + 2] = __uint_as_float(v.z);
+                            acc[mt][nt][4 * g4 + 3] = __uint_as_float(v.w);
+                        }
+                    }
+                }
+            rows_in(tid, tbuf, tcin, 2 * H2);
+            bias_add<ET, MTW, NTW>(trunk, bf);
+            pm_block_sync();
+            {
+                const int t2 = fresh_tid();
+                if (more)
+                    rows_request(t2, pre, 32 + H2 * (karg->dil[J][it + 1] - 1),
+                                 SB + GE::OFF_AC + (it + 1) * GE::CA * S, dead);
+                else if (POS < 2)
+                    strip_request(t2, pre, c0 + NC);
+                else if (c0 + NC - skew < e0)
+                    strip_request(t2, pre, c0 + 2 * NC);
+                const frag_t* w2 = stream_of(karg->w2[J][it], t2);
+                const frag_t* w1n =
+                    stream_of(karg->w1[J][more ? it + 1 : it], t2);
+                const int col_off = col_offset(t2);
+#pragma unroll 1
+                for (int c = 0; c < NCH; ++c)
+                    mma_taps<ET, K, KC, MTW, NTW, G, S, NoHook, PM_SKEW_BD>(
+                        trunk, tbuf + col_off + c * CH * ET::ESZ, S,
+                        w2 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
+                        c + 1 < NCH ? w2 + (size_t)(c + 1) * W_CHUNK
+                                    : (more ? w1n : nullptr));
+            }
+            const int te = fresh_tid();
+            const int ln2 = te & 31, lh2 = (te >> 5) & 1;
+            const unsigned lane_slot = (unsigned)((te & 63) * 16);
+            if (more)
+                load_bias_frags<ET, MTW>(
+                    bf, stream_of(karg->w1[J][it + 1], te) + W_BIAS, W_MT_STRIDE);
+            rows_out(te, tbuf + NC * S, 2 * H2, SB + GE::OFF_TC + it * 2 * H2 * S);
+            if (more) {
+                pm_block_sync();
+                if (wn + 1 < WN) {
+                    char* slot = tbuf +
+                        (2 * H2 + (wn + 1) * NTW * 32 + (te & 63)) * S +
+                        m_first * ET::ESZ;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4)
+                            *reinterpret_cast<float4*>(
+                                slot + mt * 32 * ET::ESZ + g4 * 16) =
+                                acc_quad(trunk[mt][NTW - 1], g4);
+                } else {
+                    const unsigned xo = SB +
+                        (unsigned)(((par * 2 + it) * WM + wm) * TB) + lane_slot;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const floatx16& v = trunk[mt][NTW - 1];
+                            const pm_u4 u = {__float_as_uint(v[4 * g4 + 0]),
+                                             __float_as_uint(v[4 * g4 + 1]),
+                                             __float_as_uint(v[4 * g4 + 2]),
+                                             __float_as_uint(v[4 * g4 + 3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                u, srsrc, xo + mt * 4096 + g4 * 1024, 0, 0);
+                        }
+                }
+                const int dn = karg->dil[J][it + 1];
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const int col_first = (wn * NTW + nt) * 32;
+                        store_tile_lrelu<ET>(
+                            abuf + (AL + 32 + col_first + ln2) * S,
+                            m_first + mt * 32, trunk[mt][nt], o + col_first, L,
+                            ln2, lh2);
+                    }
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = NTW - 1; nt > 0; --nt)
+                        trunk[mt][nt] = trunk[mt][nt - 1];
+                rows_in(te, abuf + (AL + H2 - H2 * dn) * S, pre,
+                        32 + H2 * (dn - 1));
+                pm_block_sync();
+                if (wn > 0) {
+                    const char* slot = tbuf +
+                        (2 * H2 + wn * NTW * 32 + (te & 63)) * S +
+                        m_first * ET::ESZ;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const float4 v = *reinterpret_cast<const float4*>(
+                                slot + mt * 32 * ET::ESZ + g4 * 16);
+                            trunk[mt][0][4 * g4 + 0] = v.x;
+                            trunk[mt][0][4 * g4 + 1] = v.y;
+                            trunk[mt][0][4 * g4 + 2] = v.z;
+                            trunk[mt][0][4 * g4 + 3] = v.w;
+                        }
+                } else {
+                    const unsigned xi = SB +
+                        (unsigned)((((par ^ 1) * 2 + it) * WM + wm) * TB) + dead;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const pm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                srsrc, xi + lane_slot + mt * 4096 + g4 * 1024, 0,
+                                AUX);
+                            trunk[mt][0][4 * g4 + 0] = __uint_as_float(v.x);
+                            trunk[mt][0][4 * g4 + 1] = __uint_as_float(v.y);
+                            trunk[mt][0][4 * g4 + 2] = __uint_as_float(v.z);
+                            trunk[mt][0][4 * g4 + 3] = __uint_as_float(v.w);
+                        }
+                }
+            }
+        }
+
+        // ---- the Block's result on [c0 - 64, c0 - 64 + NC): into the sum ----
+        if constexpr (POS == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) sum[mt][nt] = trunk[mt][nt];
+        } else if constexpr (POS == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) sum[mt][nt] += trunk[mt][nt];
+        } else {
+            // store (sum of the three) * scale, clipped to the segment:
+            // out-of-range rows are dropped by the descriptor
+            const int o = c0 - skew;
+            const int ts = fresh_tid();
+            const int ln = ts & 31, lh = (ts >> 5) & 1;
+            const int own_first = max(s0, o);
+            const int own_n = min(e0, o + NC) - own_first;
+            const float scale = p.scale;
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                p.out + ((size_t)b * p.L + own_first) * C, 0,
+                max(own_n, 0) * C * 4, 0x00020000);
+            const unsigned ovoff0 = (unsigned)(
+                ((o - own_first + wn * NTW * 32 + ln) * C + m_first + 4 * lh) * 4);
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const unsigned voff =
+                        ovoff0 + (unsigned)((mt * 32 + nt * 32 * C) * 4);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const pm_u4 r = {
+                            __float_as_uint((sum[mt][nt][4 * g4 + 0] +
+                                             trunk[mt][nt][4 * g4 + 0]) * scale),
+                            __float_as_uint((sum[mt][nt][4 * g4 + 1] +
+                                             trunk[mt][nt][4 * g4 + 1]) * scale),
+                            __float_as_uint((sum[mt][nt][4 * g4 + 2] +
+                                             trunk[mt][nt][4 * g4 + 2]) * scale),
+                            __float_as_uint((sum[mt][nt][4 * g4 + 3] +
+                                             trunk[mt][nt][4 * g4 + 3]) * scale)};
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            r, orsrc, voff + g4 * 32, 0, 0);
+                    }
+                }
+        }
+    };
+
+    typedef std::integral_constant<int, 0> P0;
+    typedef std::integral_constant<int, 1> P1;
+    typedef std::integral_constant<int, 2> P2;
+#pragma unroll 1
+    for (int c0 = s0 == 0 ? -32 : s0 - H; c0 - skew < e0;
+         c0 += NC, left = 1, par ^= 1) {
+        block_step(std::integral_constant<int, 11>(), P0(), c0);
+        block_step(std::integral_constant<int, 7>(), P1(), c0);
+        block_step(std::integral_constant<int, 3>(), P2(), c0);
+    }
 }

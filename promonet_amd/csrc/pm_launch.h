@@ -25,6 +25,10 @@
 #ifndef PM_A2_SKEW
 #define PM_A2_SKEW 1
 #endif
+// the skewed whole-MRF walk for those types (-DPM_MRF_SKEW=0: A/B builds)
+#ifndef PM_MRF_SKEW
+#define PM_MRF_SKEW 1
+#endif
 constexpr bool pm_x3skew_id(int id) {
     return id == 3 || (PM_A2_SKEW && id == 4) || (PM_X3SKEW_F32 && id == 0) ||
            (PM_SKEW16_C32 && (id == 1 || id == 2));
@@ -470,6 +474,52 @@ static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stre
         m.k[j].timeline = nullptr;
 #endif
     }
+    // Skewed whole-MRF walk (conv_mrf_skew_kernel): the operand layouts that
+    // run this stage Block by Block on the skewed walk (pm_x3skew_id), when
+    // the caller hands scratch over and the grid fills the chip several times
+    if constexpr (PM_MRF_SKEW && pm_x3skew_id(ET::ID) && C == 32 &&
+                  WM * WN == 8 && NTW >= 2) {
+        typedef MrfSkewGeom<ET, C, WM, WN, NTW> MG;
+        static_assert(MG::SCRATCH <= PM_SKEW_WG_SCRATCH, "scratch bound");
+        const int cus = pm_device_cus();
+        const int forced = pm_force().walk_nseg;
+        const Block3Args& a = blocks[0];
+        bool fits = MG::SMEM <= 160 * 1024 && a.scratch &&
+                    (cus > 0 || forced) && pm_force().skew >= 0;
+        for (int j = 0; j < 3; ++j) {
+            fits = fits && blocks[j].niter == 3;
+            for (int i = 0; i < 3 && fits; ++i)
+                fits = blocks[j].dil[i] >= 1 && blocks[j].dil[i] <= 5 &&
+                       ((KS[j] - 1) / 2) * (blocks[j].dil[i] + 1) <= 30;
+        }
+        if (fits) {
+            int nseg = forced ? forced : cus / a.B;
+            if (nseg < 1) nseg = 1;
+            const size_t need = (size_t)a.B * nseg * MG::SCRATCH;
+            if ((forced || (a.L / NC) / nseg >= 4) && need <= a.scratch_bytes) {
+                MrfSkewArgs p = {};
+                p.x = a.x; p.out = a.out;
+                for (int j = 0; j < 3; ++j)
+                    for (int n = 0; n < 3; ++n) {
+                        p.w1[j][n] = blocks[j].w1[n];
+                        p.w2[j][n] = blocks[j].w2[n];
+                        p.dil[j][n] = blocks[j].dil[n];
+                    }
+                p.B = a.B; p.L = a.L; p.halo = halo; p.scale = a.scale;
+                p.lengths = a.lengths; p.len_scale = a.len_scale;
+                p.nseg = nseg; p.wg_scratch = MG::SCRATCH;
+                p.scratch = a.scratch;
+                auto kern = conv_mrf_skew_kernel<ET, C, WM, WN, NTW>;
+                hipError_t e = pm_ensure_dynamic_lds(
+                    reinterpret_cast<const void*>(kern), MG::SMEM);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(a.B * nseg), dim3(WM * WN * 64),
+                                   MG::SMEM, stream, p);
+                return hipGetLastError();
+            }
+        }
+    }
+    if (blocks[0].skew_only) return hipErrorNotSupported;
     // Walked variant (no left-halo recompute): one workgroup per (utterance,
     // segment) with enough tiles per segment to amortise its two-sided first
     // tile; the sum-in-registers geometry (C = 32) only. (Split-f16 operands,

@@ -491,6 +491,48 @@ def test_whole_mrf(device, dtype, channels):
                 assert torch.equal(outs[0], outs[1]), (nseg, length)
         finally:
             _lib.check(_lib.lib().pm_debug_force(0, 0))
+    if dtype in ('fp32', 'f16x3', 'f16a2'):
+        # the SKEWED whole-MRF walk of the 4-byte operand layouts
+        # (conv_mrf_skew_kernel: three skewed Blocks per window, their sum in
+        # registers), taken when scratch sits behind the weights; forced with
+        # 1, 2 and 3 segments: uneven segments, a segment shorter than a step,
+        # an utterance shorter than the skew. Against the oracle and against
+        # the stand-alone two-sided tiling of the same launch without scratch
+        # (same sum order (B11 + B7 + B3) / 3: bit for bit).
+        scratch = _lib.lib().pm_walk_scratch_bytes(2)
+        big = torch.empty(ws.numel() + scratch, dtype=torch.uint8, device=device)
+        try:
+            for nseg, length in ((1, 3000), (2, 9973), (3, 12000), (2, 700),
+                                 (1, 40)):
+                x = torch.randn(2, channels, length, generator=gen)
+                want = oracle.residual_block(x, state, 'p')
+                x_cl = to_cl(x).to(device)
+                outs = []
+                for force, buffer in ((nseg, big), (0, ws)):
+                    _lib.check(_lib.lib().pm_debug_force(force, 0))
+                    out = torch.full_like(x_cl, 7.)
+                    _lib.check(_lib.lib().pm_mrf_cl(
+                        _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(out),
+                        pointers('w1'), pointers('b1'), pointers('w2'),
+                        pointers('b2'), dil, 3, 2, length, channels,
+                        buffer.data_ptr(), buffer.numel(), _lib.stream()))
+                    torch.cuda.synchronize()
+                    outs.append(out)
+                got = from_cl(outs[0], channels).cpu()
+                check(rel_err(got, want), TOL_MRF[dtype], f'mrf:{dtype}',
+                      ('skewed', channels, nseg, length))
+                assert torch.equal(outs[0], outs[1]), (nseg, length)
+                again = torch.full_like(x_cl, 7.)
+                _lib.check(_lib.lib().pm_debug_force(nseg, 0))
+                _lib.check(_lib.lib().pm_mrf_cl(
+                    _lib.DTYPES[dtype], _lib.ptr(x_cl), _lib.ptr(again),
+                    pointers('w1'), pointers('b1'), pointers('w2'),
+                    pointers('b2'), dil, 3, 2, length, channels,
+                    big.data_ptr(), big.numel(), _lib.stream()))
+                torch.cuda.synchronize()
+                assert torch.equal(again, outs[0])
+        finally:
+            _lib.check(_lib.lib().pm_debug_force(0, 0))
     with pytest.raises(RuntimeError):
         x_cl = torch.zeros(1, 8, 64, device=device)
         _lib.check(_lib.lib().pm_mrf_cl(
