@@ -1140,7 +1140,11 @@ __device__ __forceinline__ void block3_body(
     // (weight-fragment prefetch depth in k16 steps; a split-f16 step is three
     // MFMAs per tile - 192+ cycles at two tiles per wave -, so one step ahead
     // covers the L2 round trip and depth 2 spilled at C = 32 k 11)
-    constexpr int G = (ET::ESZ == 4) ? (ET::SPLIT && NTW >= 2 ? 1 : 2) : KC;
+#ifndef PM_K3_G
+#define PM_K3_G 0       // (A/B builds: weight prefetch depth of the k 3 whole-Block kernels at C >= 128)
+#endif
+    constexpr int G = (ET::ESZ == 4) ? (ET::SPLIT && NTW >= 2 ? 1 : 2)
+                    : (PM_K3_G && K == 3 && C >= 128 ? PM_K3_G : KC);
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;          // bias step of a stream
     constexpr int W_MT_STRIDE = W_BIAS + 64;

@@ -283,7 +283,10 @@ template <> struct Block3Cfg<ElemF16, 32, 11>  { enum { WM = 1, WN = 8, NTW = 3 
 template <> struct Block3Cfg<ElemF16, 64, 3>   { enum { WM = 2, WN = 2, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 64, 7>   { enum { WM = 2, WN = 4, NTW = 4 }; };
 template <> struct Block3Cfg<ElemF16, 64, 11>  { enum { WM = 2, WN = 4, NTW = 4 }; };
-template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 2, NTW = 4 }; };
+#ifndef PM_K3_NTW
+#define PM_K3_NTW 4     // (A/B builds: 3 tiles per wave at C = 128 k 3)
+#endif
+template <> struct Block3Cfg<ElemF16, 128, 3>  { enum { WM = 4, WN = 2, NTW = PM_K3_NTW }; };
 // C = 128, k 7: walked only (conv_block3_walk_kernel; stand-alone, the 36-column
 // halo on both sides of a 256-column tile made it 28 % slower than three pair
 // launches - walked it is 10.6 % faster, profiles/r02/ab_block128_k7_walk.txt)
