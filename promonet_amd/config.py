@@ -82,15 +82,19 @@ FARGAN_SUBFRAMES = 4
 # the random-init output scale (audio peak 0.017: what BASELINE.json's 1e-4
 # gate is stated on) | with the output conv rescaled so that the audio peaks at
 # 0.5 | at 0.99, a trained checkpoint's scale, and the batch-32 x 10 s step:
-#   'checkpoint'      3.0e-7 | 1.2e-5 | 4.9e-5   22.2 ms  (DEFAULT) f16, the last
-#                     upsampling stage with SPLIT f16 operands ('f16x3': hi + lo,
-#                     three MFMAs per step, ~21 bits per factor): the mode that
-#                     holds 1e-4 at a real checkpoint's output scale. Spelled
-#                     out for the default 4-stage model: 'f16+f16+f16+f16x3'
-#   'f16'             3.1e-6 | 7.2e-5 | 3.5e-4   19.2 ms  operands saturate at 65504
-#   'bf16'            3.0e-5 | 7.7e-4 |   -      18.0 ms  what BASELINE.json config 3
+#   'checkpoint'      5e-7   | 1.5e-5 | 5.7e-5   20.1 ms  (DEFAULT) f16; in the last
+#                     upsampling stage the ACTIVATIONS split into hi + lo ('f16a2':
+#                     two MFMAs per step in its Blocks, its upsampler fully split),
+#                     the upsampler of the stage before it fully split too ('f16ux'):
+#                     the mode that holds 1e-4 at a real checkpoint's output scale.
+#                     Spelled out for the default 4-stage model: 'f16+f16+f16ux+f16a2'
+#   'f16+f16+f16+f16x3'  4e-7 | 1.3e-5 | 5.2e-5   21.3 ms  the last stage fully split
+#                     (hi + lo of both operands, three MFMAs per step): the default
+#                     until round 6
+#   'f16'             3.1e-6 | 7.2e-5 | 3.9e-4   18.4 ms  operands saturate at 65504
+#   'bf16'            3.0e-5 | 7.7e-4 |   -      17.6 ms  what BASELINE.json config 3
 #                     names and bench.py asks for; fp32's exponent range
-#   'fp32'            5.4e-8 | 2.0e-6 | 8.7e-6   ~150 ms  exact-fp32 MFMA, 1/16 rate
+#   'fp32'            5.4e-8 | 2.0e-6 | 8.7e-6   ~145 ms  exact-fp32 MFMA, 1/16 rate
 #   'f16x3'           split f16 everywhere (fp32-like, ~3x the f16 step)
 #   one type per upsampling stage joined by '+', e.g. 'bf16+bf16+bf16+f16'
 #                     (1.2e-4 at peak 0.5, at bf16's speed)

@@ -27,7 +27,7 @@ for seed in range(1, 1 + (int(sys.argv[1]) if len(sys.argv) > 1 else 4)):
         state[key] = state[key] * (math.atanh(.99) / math.atanh(peak))
         want = oracle.generator_forward(*inputs, state)
     row = {}
-    for dtype in ('checkpoint', 'f16', 'fp32'):
+    for dtype in ('checkpoint', 'f16+f16+f16+f16x3', 'f16', 'fp32'):
         promonet_amd.configure(COMPUTE_DTYPE=dtype)
         model = promonet_amd.model.Generator()
         model.load_state_dict(state)
