@@ -320,7 +320,7 @@ def kernel_label(name):
     m = re.search(r'conv_block3(?:_walk|_skew)?_kernel<\w+,(\d+),(\d+),', name)
     if m:
         return f'block_c{m.group(1)}_k{m.group(2)}'
-    m = re.search(r'conv_mrf(?:_walk)?_kernel<\w+,(\d+),', name)
+    m = re.search(r'conv_mrf(?:_walk|_skew)?_kernel<\w+,(\d+),', name)
     if m:
         return f'mrf_c{m.group(1)}'
     if 'pm_out_conv' in name:
@@ -1100,8 +1100,9 @@ def main():
             if world == 1:
                 try:
                     sustained_peak = mfma_probe(operand, device)
-                    if sustained_peak and operand == 'f16x3':
-                        sustained_peak /= 3.     # per USEFUL flop
+                    if sustained_peak and operand in ('f16x3', 'f16a2'):
+                        # per USEFUL flop (three / two MFMAs per product)
+                        sustained_peak /= 3. if operand == 'f16x3' else 2.
                 except Exception as error:          # noqa: BLE001
                     sys.stderr.write(f'bench.py: mfma probe failed: {error}\n')
             table, traffic_source = None, None

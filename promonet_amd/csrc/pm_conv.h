@@ -335,6 +335,15 @@ __device__ __forceinline__ float4 acc_quad(const floatx16& v, const int g4) {
 // stores this replaces were 2-way conflicted (rows r and r + 8 on one bank:
 // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 18-20 % in the whole-Block kernels).
 // `rowp` = the lane's row in the LDS tile, `ch` = the tile's first channel.
+// Split (hi + lo) operand tiles: 1 = a lane stores its four channels' hi and lo
+// parts as two 8-byte pieces (2-way bank conflicted at the 144-byte pitch); 0 =
+// the half-waves exchange first and every lane stores ONE conflict-free 16-byte
+// block. Measured: the exchange (8 more v_permlane32_swap a tile) costs more
+// than the conflicts - A2 whole-MRF 4.07 vs 3.88-3.99 ms, x3 5.34 vs 5.26
+// (profiles/r06/ab_split_store.txt) - so 1 ships.
+#ifndef PM_SPLIT_STORE8
+#define PM_SPLIT_STORE8 1
+#endif
 template <class ET, bool MASK>
 __device__ __forceinline__ void store_tile_lrelu_impl(
     char* rowp, const int ch, const floatx16& v, const bool zero,
@@ -354,6 +363,24 @@ __device__ __forceinline__ void store_tile_lrelu_impl(
             // lanes < 32: [own quad g4 | upper half's quad g4] = channels
             // 8 g4 .. 8 g4 + 7; lanes >= 32: [lower's g4 + 1 | own g4 + 1]
             *reinterpret_cast<uint4*>(rowp + (ch + 8 * (g4 + lh)) * 2) =
+                make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+    } else if constexpr (ET::SPLIT && !PM_SPLIT_STORE8) {
+        // (A/B form, see PM_SPLIT_STORE8) hi + lo layout - an 8-channel group =
+        // [8 x hi | 8 x lo], 32 bytes: lanes < 32 take the group's 16-byte hi
+        // block, lanes >= 32 its lo block, one ds_write_b128 each
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float4 q = pm_lrelu4(acc_quad(v, g4));
+            if (MASK && zero) q = make_float4(0.f, 0.f, 0.f, 0.f);
+            half4 hi, lo;
+            ElemF16X3::split4(q, hi, lo);
+            const uint2 a = __builtin_bit_cast(uint2, hi);
+            const uint2 b = __builtin_bit_cast(uint2, lo);
+            auto sx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+            auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+            // lanes < 32: [own hi | upper half's hi]; >= 32: [lower's lo | own lo]
+            *reinterpret_cast<uint4*>(rowp + ((ch >> 3) + g4) * 32 + lh * 16) =
                 make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
     } else {
