@@ -522,7 +522,13 @@ static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stre
             }
         }
     }
-    if (blocks[0].skew_only) return hipErrorNotSupported;
+    // (skew_only: the caller prefers Block-by-Block skewed launches to the
+    // two-sided tiling below - except when the test hook has switched the
+    // skewed walk off altogether: then this launch, whose sum order is the
+    // skewed whole-MRF walk's, is the stand-alone counterpart the tests compare
+    // bit for bit)
+    if (blocks[0].skew_only && pm_force().skew >= 0)
+        return hipErrorNotSupported;
     // Walked variant (no left-halo recompute): one workgroup per (utterance,
     // segment) with enough tiles per segment to amortise its two-sided first
     // tile; the sum-in-registers geometry (C = 32) only. (Split-f16 operands,

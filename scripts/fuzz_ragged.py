@@ -39,7 +39,7 @@ promonet_amd.configure(COMPUTE_DTYPE=promonet_amd.config.DEFAULT_COMPUTE_DTYPE)
 
 bad = 0
 for trial in range(trials):
-    dtype = ('bf16', 'f16', 'fp32')[trial % 3]
+    dtype = ('bf16', 'f16', 'fp32', 'checkpoint')[trial % 4]
     model = models[dtype]
     batch = rng.randint(max(1, max_batch // 2), max_batch)
     # (a few long utterances in a small batch: the walked kernels with many

@@ -723,12 +723,14 @@ def test_ragged_batch_is_exact(device, default_state):
           'ragged_vs_oracle:f16')
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('dtype', ['bf16', 'f16', 'checkpoint', 'fp32'])
 def test_walked_kernels_match_standalone_tiling(device, default_state, dtype):
     """A few long utterances in one batch run the walked whole-Block / MRF
     kernels (one workgroup per utterance segment, left halo carried through
-    LDS); each utterance alone runs the stand-alone tiling. Same arithmetic per
-    column: bit-identical, tails zero."""
+    LDS; the 4-byte operand layouts of 'checkpoint' / 'fp32': the SKEWED
+    whole-MRF walk of the last stage, conv_mrf_skew_kernel, carries through
+    scratch); each utterance alone runs the stand-alone tiling. Same arithmetic
+    per column, same order of the MRF sum: bit-identical, tails zero."""
     model = make_model(default_state, dtype, device)
     lengths = [2300, 700, 1500]
     frames = max(lengths)
