@@ -240,7 +240,10 @@ int pm_block_act16_cl(int dtype, int act_dtype, const float* x_cl,
  * out = (Block_3(x) + Block_7(x) + Block_11(x)) / 3 in one launch, the sum
  * held in registers (32 channels). w1/b1/w2/b2: HOST arrays of 3 * niter
  * device pointers, Block-major (k = 3 first);
- * workspace >= 3 * niter * pm_op_workspace_bytes(c, c, 11)                  */
+ * workspace >= 3 * niter * pm_op_workspace_bytes(c, c, 11); with
+ * pm_walk_scratch_bytes(batch) more behind it the 4-byte operand layouts
+ * (PM_F32, PM_F16X3, PM_F16A2) take the skewed whole-MRF walk on long batches
+ * (three skewed Blocks per window, nothing recomputed)                      */
 int pm_mrf_cl(int dtype, const float* x_cl, float* out_cl,
               const float* const* w1, const float* const* b1,
               const float* const* w2, const float* const* b2,

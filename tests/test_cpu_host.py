@@ -79,6 +79,25 @@ def test_engine_create_validates_configuration():
     bad = make_config(compute_dtype=7)
     assert library.pm_hifigan_create(
         ctypes.byref(bad), ctypes.byref(handle)) == -1
+    # the stage types of the 'checkpoint' schedule (promonet_hip.h: PM_F16A2 =
+    # activations split, PM_F16UX = f16 Blocks behind a fully split upsampler)
+    # are accepted per engine and per stage; one past them is not
+    from promonet_amd.model.hifigan import checkpoint_schedule
+    assert checkpoint_schedule(4) == ['f16', 'f16', 'f16ux', 'f16a2']
+    assert checkpoint_schedule(2) == ['f16ux', 'f16a2']
+    assert checkpoint_schedule(1) == ['f16a2']
+    assert (_lib.PM_F16A2, _lib.PM_F16UX) == (4, 5)
+    good = make_config(compute_dtype=_lib.PM_F16)
+    good.stage_compute_dtype[2] = 1 + _lib.PM_F16UX
+    good.stage_compute_dtype[3] = 1 + _lib.PM_F16A2
+    assert library.pm_hifigan_create(
+        ctypes.byref(good), ctypes.byref(handle)) == 0
+    assert library.pm_hifigan_destroy(handle) == 0
+    bad = make_config()
+    bad.stage_compute_dtype[3] = 2 + _lib.PM_F16UX
+    assert library.pm_hifigan_create(
+        ctypes.byref(bad), ctypes.byref(handle)) == -1
+    assert b'stage_compute_dtype[3]' in library.pm_last_error()
     bad = make_config()
     bad.resblock_dilations[0][2] = 9
     assert library.pm_hifigan_create(
