@@ -2422,6 +2422,7 @@ struct MrfSkewArgs {
     int nseg;               // segments per utterance
     int wg_scratch;         // bytes of scratch per workgroup
     char* scratch;
+    PM_TIMELINE_FIELD       // debug phase totals (tuning builds)
 };
 
 template <class ET, int C, int WM, int WN, int NTW>
@@ -2539,6 +2540,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
     };
     pm_u4 pre[PRE];
     int left = 0, par = 0;
+#ifdef PM_TUNING
+    // phase totals of wave 0 per Block (shader clocks): 0 stage, 1 conv1,
+    // 2 epilogue 1, 3 its barrier, 4 conv2, 5 epilogue 2 + hand-over, 7 its
+    // barrier, 8 sum / store, 9 steps
+    unsigned long long ph[3][10] = {};
+    unsigned long long last_mark = __builtin_amdgcn_s_memtime();
+#define PM_MRF_MARK(k)                                                        \
+    do {                                                                      \
+        const unsigned long long now = __builtin_amdgcn_s_memtime();          \
+        ph[POS][k] += now - last_mark; last_mark = now;                       \
+    } while (0)
+#else
+#define PM_MRF_MARK(k) ((void)0)
+#endif
 
     // One Block (kernel size KV::value) on the window of this step. POS: 0 the
     // first Block of the step (x and the strip come from the previous STEP's
@@ -2637,6 +2652,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the Block kernel
         pm_block_sync();
+        PM_MRF_MARK(0);
 
 #pragma unroll 1
         for (int it = 0; it < 3; ++it) {
@@ -2660,6 +2676,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
                         d * S, w1 + (size_t)c * W_CHUNK, W_MT_STRIDE, afirst,
                         c + 1 < NCH ? w1 + (size_t)(c + 1) * W_CHUNK : w2);
             }
+            PM_MRF_MARK(1);
             const int tid = fresh_tid();
             const int ln = tid & 31, lh = (tid >> 5) & 1;
             load_bias_frags<ET, MTW>(
@@ -2705,7 +2722,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
                 }
             rows_in(tid, tbuf, tcin, 2 * H2);
             bias_add<ET, MTW, NTW>(trunk, bf);
+            PM_MRF_MARK(2);
             pm_block_sync();
+            PM_MRF_MARK(3);
             {
                 const int t2 = fresh_tid();
                 if (more)
@@ -2727,6 +2746,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
                         c + 1 < NCH ? w2 + (size_t)(c + 1) * W_CHUNK
                                     : (more ? w1n : nullptr));
             }
+            PM_MRF_MARK(4);
             const int te = fresh_tid();
             const int ln2 = te & 31, lh2 = (te >> 5) & 1;
             const unsigned lane_slot = (unsigned)((te & 63) * 16);
@@ -2781,7 +2801,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
                         trunk[mt][nt] = trunk[mt][nt - 1];
                 rows_in(te, abuf + (AL + H2 - H2 * dn) * S, pre,
                         32 + H2 * (dn - 1));
+                PM_MRF_MARK(5);
                 pm_block_sync();
+                PM_MRF_MARK(7);
                 if (wn > 0) {
                     const char* slot = tbuf +
                         (2 * H2 + wn * NTW * 32 + (te & 63)) * S +
@@ -2863,6 +2885,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
                     }
                 }
         }
+        PM_MRF_MARK(8);
+#ifdef PM_TUNING
+        ph[POS][9] += 1;
+#endif
     };
 
     typedef std::integral_constant<int, 0> P0;
@@ -2875,4 +2901,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
         block_step(std::integral_constant<int, 7>(), P1(), c0);
         block_step(std::integral_constant<int, 3>(), P2(), c0);
     }
+#ifdef PM_TUNING
+    if (p.timeline && threadIdx.x == 0)
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 10; ++i)
+                p.timeline[((size_t)blockIdx.x * 3 + j) * 16 + i] = ph[j][i];
+#endif
 }

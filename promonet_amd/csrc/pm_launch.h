@@ -512,6 +512,9 @@ static hipError_t launch_mrf_cfg(const Block3Args (&blocks)[3], hipStream_t stre
                 p.lengths = a.lengths; p.len_scale = a.len_scale;
                 p.nseg = nseg; p.wg_scratch = MG::SCRATCH;
                 p.scratch = a.scratch;
+#ifdef PM_TUNING
+                p.timeline = blocks[0].timeline;
+#endif
                 auto kern = conv_mrf_skew_kernel<ET, C, WM, WN, NTW>;
                 hipError_t e = pm_ensure_dynamic_lds(
                     reinterpret_cast<const void*>(kern), MG::SMEM);
