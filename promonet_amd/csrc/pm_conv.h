@@ -1829,6 +1829,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_walk_kernel(
 // 32 (niter - 1) columns past the segment. Same arithmetic per column as
 // every other tiling of the Block (tests: bit-identical).
 // ---------------------------------------------------------------------------
+// Weight-fragment prefetch depth (k16 steps) of the skewed kernels' MFMA loops:
+// a conv's whole chunk for the 16-bit types; exact fp32 two steps; split f16 one
+// (depth 2 spills at k 11 and measures the same) - except ElemF16A2, whose
+// weight fragments are the 16-byte ones of f16: two steps
+// (-3.7 % at k 11 over depth 1: profiles/r06/ab_a2g2.txt)
+#ifndef PM_A2_SKEW_G
+#define PM_A2_SKEW_G 2
+#endif
+template <class ET>
+__host__ __device__ constexpr int pm_skew_prefetch_depth(int kc) {
+    return ET::ESZ == 4
+        ? (ET::SPLIT ? (ET::WSZ == 2 ? PM_A2_SKEW_G : 1) : 2) : kc;
+}
+
 struct Block3SkewArgs {
     Block3Args a;
     int nseg;               // segments per utterance
@@ -1871,11 +1885,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_block3_skew_kernel(
     constexpr int QS = S / 16;
     // (split f16: weight prefetch depth 1 - depth 2 spills at k 11 and measures
     // the same; its B fragments two steps deep: -3 % at k 11, profiles/r04/ab_x3_skew.txt)
-#ifndef PM_A2_SKEW_G
-#define PM_A2_SKEW_G 2     // (-3.7 % at k 11 over depth 1: profiles/r06/ab_a2g2.txt)
-#endif
-    constexpr int G = (ET::ESZ == 4)
-        ? (ET::SPLIT ? (ET::WSZ == 2 ? PM_A2_SKEW_G : 1) : 2) : KC;
+    constexpr int G = pm_skew_prefetch_depth<ET>(KC);
     constexpr int W_CHUNK = K * KC * 64;
     constexpr int W_BIAS = NCH * W_CHUNK;
     constexpr int W_MT_STRIDE = W_BIAS + 64;
@@ -2446,8 +2456,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mrf_skew_kernel(
     constexpr int NT = WM * WN * 64;
     constexpr int S = C * ET::ESZ + 16;
     constexpr int QS = S / 16;
-    constexpr int G = (ET::ESZ == 4)
-        ? (ET::SPLIT ? (ET::WSZ == 2 ? PM_A2_SKEW_G : 1) : 2) : KC;
+    constexpr int G = pm_skew_prefetch_depth<ET>(KC);
     constexpr int AUX = 16;        // sc1: served by the L2, never by this CU's L1
     constexpr int PM_SKEW_BD = ET::SPLIT ? 2 : 0;
     constexpr int TB = MTW * 4096;
