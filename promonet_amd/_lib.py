@@ -100,6 +100,7 @@ SIGNATURES = {
     'pm_stft_mel_prepare': (_I, [_P, _I, _P, _S, _P]),
     'pm_stft_mel': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     'pm_stft_set_frames_per_group': (_I, [_I]),
+    'pm_stft_set_loudness_passes': (_I, [_I]),
     'pm_stft_launch_info': (_I, [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     'pm_linear_to_mel': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'pm_stft_backward_scratch_bytes': (_S, [_I, _I]),

@@ -1674,6 +1674,21 @@ static int get_fft_tables(const float** out, hipStream_t s) {
     return PM_OK;
 }
 
+// 2 (default): both transforms for every frame; 1: the 8-band loudness runs the
+// OPTIMISTIC first pass and transforms a group a second time only where the
+// floor bites. Opt-in because it depends on the material: noise at a steady
+// level 56 -> 47 us (batch 32 x 10 s), but a group with ANY bin more than 80 dB
+// under its utterance's maximum is transformed twice by a first pass that costs
+// what the second does (36 + 34 us against 27 + 34 when every group is) - and
+// 16 frames x 513 bins of recorded speech usually hold such a bin.
+static thread_local int g_loudness_passes = 2;
+extern "C" int pm_stft_set_loudness_passes(int passes) {
+    if (passes != 1 && passes != 2)
+        return fail(PM_EINVAL, "loudness passes: 1 (optimistic) or 2");
+    g_loudness_passes = passes;
+    return PM_OK;
+}
+
 extern "C" int pm_stft_set_frames_per_group(int frames) {
     if (frames != 16 && frames != 32)
         return fail(PM_EINVAL, "frames per workgroup must be 16 or 32");
@@ -1748,8 +1763,8 @@ static int fft_launch(FftArgs& a, hipStream_t s,
 // The geometry the next launch of one FFT transform would take on this device
 // and host thread (tests assert that the persistent multi-group walk - more
 // groups than resident workgroups - is what they exercise). transform: 1
-// magnitude, 4 log-mel, 2 / 3 / 5 the loudness passes (maximum, generic bands,
-// the 8 default bands).
+// magnitude, 4 log-mel, 2 / 3 / 5 / 6 the loudness passes (maximum, generic
+// bands, the 8 default bands, their optimistic first pass).
 extern "C" int pm_stft_launch_info(
     int transform, int B, int N, int* total_groups, int* workgroups) {
     if (!total_groups || !workgroups) return fail(PM_EINVAL, "null argument");
@@ -1762,7 +1777,8 @@ extern "C" int pm_stft_launch_info(
         case 3: rc = fft_launch<3>(a, nullptr, g_fft_frames_per_group, &grid); break;
         case 4: rc = fft_launch<4>(a, nullptr, g_fft_frames_per_group, &grid); break;
         case 5: rc = fft_launch<5>(a, nullptr, g_fft_frames_per_group, &grid); break;
-        default: return fail(PM_EINVAL, "transform must be 1..5");
+        case 6: rc = fft_launch<6>(a, nullptr, g_fft_frames_per_group, &grid); break;
+        default: return fail(PM_EINVAL, "transform must be 1..6");
     }
     if (rc) return rc;
     *total_groups = a.total;
@@ -1907,15 +1923,22 @@ extern "C" int pm_linear_to_mel(
 
 extern "C" size_t pm_loudness_scratch_bytes(int B, int N) {
     if (B < 1 || N < HOP) return 0;
-    // one maximum per FFT workgroup (>= 16 frames each) and utterance
+    // one maximum and one minimum per FFT workgroup (>= 16 frames each) and
+    // utterance
     const size_t groups = ((size_t)(N / HOP) + 15) / 16;
-    return align256((size_t)B * groups * sizeof(float));
+    return 2 * align256((size_t)B * groups * sizeof(float));
 }
 
 // Two passes over the audio (4 B / sample each) instead of a (B, 513, T) dB
 // tensor written and re-read: pass 1 finds every utterance's maximum dB
 // (librosa.amplitude_to_db's top_db reference, loudness.py:46), pass 2 repeats
 // the FFT and writes the floored, A-weighted band means.
+// With pm_stft_set_loudness_passes(1) the default 8 bands run OPTIMISTICALLY:
+// pass 1 (EPI 6) already writes the band means, without a floor, and records
+// every 16-frame group's minimum dB next to its maximum; pass 2 (EPI 5)
+// transforms only the groups that have a bin under their utterance's floor -
+// for the others max(v, floor) == v and pass 1's means are final, bit for bit
+// (tests/test_gpu_preprocess_full.py). Off by default: see g_loudness_passes.
 extern "C" int pm_loudness(
     const float* audio, const float* a_weights, float* out, int B, int N,
     int bands, float min_db, void* scratch, size_t scratch_bytes,
@@ -1931,8 +1954,6 @@ extern "C" int pm_loudness(
     a.audio = audio; a.out = out; a.B = B; a.N = N;
     a.group_max = (float*)scratch;
     const int frames_per_group = g_fft_frames_per_group;   // both passes
-    int rc = fft_launch<2>(a, s, frames_per_group);
-    if (rc) return rc;
     a.weights = a_weights; a.rows = bands;
     const double step = (double)BINS / (double)bands;   // loudness.py:96
     for (int b = 0; b <= bands && b <= 16; ++b)
@@ -1946,8 +1967,17 @@ extern "C" int pm_loudness(
 #ifdef PM_LOUD_NO_EPI5
     aligned8 = false;
 #endif
-    if (aligned8 && a.band_start[8] == BINS)
+    aligned8 = aligned8 && a.band_start[8] == BINS;
+    if (aligned8 && g_loudness_passes == 1) {
+        a.group_min = (float*)((char*)scratch +
+                               pm_loudness_scratch_bytes(B, N) / 2);
+        int rc = fft_launch<6>(a, s, frames_per_group);
+        if (rc) return rc;
         return fft_launch<5>(a, s, frames_per_group);
+    }
+    int rc = fft_launch<2>(a, s, frames_per_group);
+    if (rc) return rc;
+    if (aligned8) return fft_launch<5>(a, s, frames_per_group);
     return fft_launch<3>(a, s, frames_per_group);
 }
 

@@ -36,6 +36,13 @@
 //        j (band_average's edges int(b 513 / 8) are 0, 64, ... 448, 513), so
 //        the band sums are reduced across the wave out of the registers - no
 //        513-row staging tile, 8 x FR floats of LDS instead
+// EPI 6: the OPTIMISTIC first pass of the default loudness: EPI 5's band means
+//        with no floor at all, plus what the floor needs (every group's
+//        maximum, as EPI 2) and what tells whether it would have changed
+//        anything (every group's MINIMUM dB). A bin only feels the floor when it
+//        lies more than top_db under the utterance's maximum: for a group whose
+//        minimum is not, max(v, floor) == v bit for bit and EPI 6's means are
+//        final - the second pass (EPI 5) skips it without a transform.
 #pragma once
 #include "pm_common.h"
 
@@ -63,8 +70,11 @@ struct FftArgs {
     const float* audio;      // (B, N)
     float* out;
     const float* tables;     // PM_FFT_TAB_FLOATS
-    float* group_max;        // (B, groups): every group's maximum dB (EPI 2
-                             // writes it, EPI 3 folds the utterance's row)
+    float* group_max;        // (B, groups): every group's maximum dB (EPI 2 / 6
+                             // write it, EPI 3 / 5 fold the utterance's row)
+    float* group_min;        // (B, groups) or null: every group's MINIMUM dB
+                             // (EPI 6 writes it; EPI 5 skips a group none of
+                             // whose bins lies under the floor)
     const float* weights;    // EPI 3: (513) A-weights; EPI 4: mel basis (M, 513)
     const int* mel_span;     // EPI 4: pm_mel_csr_kernel's table (lo, hi, offset
                              // per filter, then the non-zero count)
@@ -201,7 +211,8 @@ template <int EPI, int NW, int FPW>
 __host__ __device__ constexpr int pm_fft_smem_bytes() {
     constexpr int FR = NW * FPW;
     return NW * 576 * 8 +
-           (EPI == 2 ? 64 : EPI == 5 ? 8 * (FR + 1) * 4 : PM_FFT_BINS * (FR + 1) * 4) +
+           (EPI == 2 ? 64 : EPI == 5 ? 8 * (FR + 1) * 4 : EPI == 6 ? 8 * (FR + 1) * 4 + 128
+                     : PM_FFT_BINS * (FR + 1) * 4) +
            (EPI == 4 ? PM_FFT_MEL_CAP * 4 : 0);
 }
 
@@ -250,7 +261,7 @@ void pm_stft_fft_kernel(FftArgs a) {
 #ifdef PM_FFT_NO_DIRECT_DC           // (A/B builds)
     constexpr bool DIRECT_DC = false;
 #else
-    constexpr bool DIRECT_DC = EPI == 2 || EPI == 3 || EPI == 5;
+    constexpr bool DIRECT_DC = EPI == 2 || EPI == 3 || EPI == 5 || EPI == 6;
 #endif
     constexpr int WS = 576;          // complex slots per wave (8 x 72)
     constexpr int OS = FR + 1;       // staging row pitch (floats)
@@ -327,7 +338,7 @@ void pm_stft_fft_kernel(FftArgs a) {
     }
     // EPI 3 / 5: the A-weights of this lane's 8 (+ 1) bins
     [[maybe_unused]] float wlo[4], whi[4], w256 = 0.f;
-    if constexpr (EPI == 3 || EPI == 5) {
+    if constexpr (EPI == 3 || EPI == 5 || EPI == 6) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             wlo[j] = a.weights[lane + 64 * j];
@@ -335,9 +346,13 @@ void pm_stft_fft_kernel(FftArgs a) {
         }
         w256 = a.weights[256];
     }
-    [[maybe_unused]] float floor_db = 0.f;
+    [[maybe_unused]] float floor_db = EPI == 6 ? -INFINITY : 0.f;
+    // (EPI 6: an OPAQUE -inf - with the constant the compiler drops the max and
+    // contracts v + weight into the multiplication in front of it, one rounding
+    // fewer than EPI 5's mul / max / add: the two passes must agree bit for bit)
+    if constexpr (EPI == 6) asm volatile("" : "+v"(floor_db));
     [[maybe_unused]] int floor_of = -1;    // utterance floor_db belongs to
-    [[maybe_unused]] int parity = 0;       // EPI 2: reduction slots alternate
+    [[maybe_unused]] int parity = 0;       // EPI 2 / 6: reduction slots alternate
     pm_v2* wk = work + wave * WS;
 #pragma unroll 1
     for (;;) {
@@ -348,7 +363,8 @@ void pm_stft_fft_kernel(FftArgs a) {
     const int bn = more ? gn / a.groups : b;
     const int t0n = more ? (gn - bn * a.groups) * FR : t0;
     const float* __restrict__ abn = a.audio + (size_t)bn * N;
-    float local_max = EPI == 2 ? 0.f : -INFINITY;   // (EPI 2: of |X|^2 >= 0)
+    float local_max = (EPI == 2 || EPI == 6) ? 0.f : -INFINITY;   // (of |X|^2 >= 0)
+    [[maybe_unused]] float local_min = INFINITY;     // EPI 6: of the bins' dB
     if constexpr (EPI == 3 || EPI == 5) {
         if (floor_of != b) {               // (workgroup-uniform)
         // the utterance maximum of pass 1 (librosa.amplitude_to_db's top_db
@@ -367,6 +383,17 @@ void pm_stft_fft_kernel(FftArgs a) {
         __syncthreads();
         floor_db = m - a.top_db;
         floor_of = b;
+        }
+    }
+    if constexpr (EPI == 5) {
+        // behind the optimistic first pass (EPI 6): a group none of whose bins
+        // lies under the floor already has its final means - no transform
+        if (a.group_min &&
+            a.group_min[(size_t)b * a.groups + t0 / FR] >= floor_db) {
+            if (!more) break;
+            pm_fft_load_frame(raw, abn, min(t0n + wave, T - 1), N, lane);
+            g = gn; b = bn; t0 = t0n; ab = abn;
+            continue;
         }
     }
 
@@ -452,9 +479,13 @@ void pm_stft_fft_kernel(FftArgs a) {
             } else {
                 const float v = PM_DB_PER_LOG2 *
                                 __log2f(fmaxf(1e-10f, 0.25f * pw4));
+                if constexpr (EPI == 6) {
+                    local_max = fmaxf(local_max, valid ? pw4 : 0.f);
+                    local_min = fminf(local_min, valid ? v : INFINITY);
+                }
                 float u = fmaxf(v, floor_db) + weight;
                 u = u < a.min_db ? a.min_db : u;
-                if constexpr (EPI == 5) bs[band] = u;
+                if constexpr (EPI == 5 || EPI == 6) bs[band] = u;
                 else ost[k * OS + fl] = u;
             }
         };
@@ -479,20 +510,24 @@ void pm_stft_fft_kernel(FftArgs a) {
                     plo = lane == 0 ? 4.f * x_dc * x_dc : plo;
                     phi = lane == 0 ? 4.f * x_ny * x_ny : phi;
                 }
-                bin_out(plo, k, (EPI == 3 || EPI == 5) ? wlo[j] : 0.f, j);
-                bin_out(phi, 512 - k, (EPI == 3 || EPI == 5) ? whi[j] : 0.f,
+                bin_out(plo, k, (EPI == 3 || EPI >= 5) ? wlo[j] : 0.f, j);
+                bin_out(phi, 512 - k, (EPI == 3 || EPI >= 5) ? whi[j] : 0.f,
                         7 - j);
             }
         }
         {
             // bin 256 pairs with itself: |X[256]| = |Z[256]|; lane 0 takes it
             const float pw4 = 4.f * pk_norm(wk[256]);
-            if constexpr (EPI == 5) {
+            if constexpr (EPI == 5 || EPI == 6) {
                 // lane 0's partner bins 448, 384, 320 sit one band above where
                 // the other lanes' do (512 - 64 j = 64 (8 - j)): shift them up
                 // and put bin 256 into band 4
                 const float v = PM_DB_PER_LOG2 *
                                 __log2f(fmaxf(1e-10f, 0.25f * pw4));
+                if constexpr (EPI == 6) {       // (the same value in every lane)
+                    local_max = fmaxf(local_max, valid ? pw4 : 0.f);
+                    local_min = fminf(local_min, valid ? v : INFINITY);
+                }
                 float u = fmaxf(v, floor_db) + w256;
                 u = u < a.min_db ? a.min_db : u;
                 if (lane == 0) {
@@ -502,7 +537,7 @@ void pm_stft_fft_kernel(FftArgs a) {
                 bin_out(pw4, 256, w256, 4);
             }
         }
-        if constexpr (EPI == 5) {
+        if constexpr (EPI == 5 || EPI == 6) {
             // 8 sums over 64 lanes in 10 exchanges: three halving steps (a
             // lane keeps the bands of its own half and adds the partner's
             // values for them), then three plain ones; lane 8 band ends up
@@ -568,7 +603,33 @@ void pm_stft_fft_kernel(FftArgs a) {
                 PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, 0.25f * m));   // (m = 4 |X|^2)
         }
     } else {
+    if constexpr (EPI == 6) {
+        // the group's maximum |X|^2 and minimum dB: slots behind the staging
+        // rows, two alternating sets (as EPI 2)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            local_max = fmaxf(local_max, __shfl_xor(local_max, o, 64));
+            local_min = fminf(local_min, __shfl_xor(local_min, o, 64));
+        }
+        float* red = ost + 8 * OS + 16 * parity;
+        if (lane == 0) { red[wave] = local_max; red[8 + wave] = local_min; }
+    }
     __syncthreads();
+    if constexpr (EPI == 6) {
+        if (tid == 0) {
+            const float* red = ost + 8 * OS + 16 * parity;
+            float m = red[0], n = red[8];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                m = fmaxf(m, red[w]); n = fminf(n, red[8 + w]);
+            }
+            const size_t slot = (size_t)b * a.groups + t0 / FR;
+            a.group_max[slot] =
+                PM_DB_PER_LOG2 * __log2f(fmaxf(1e-10f, 0.25f * m));
+            a.group_min[slot] = n;
+        }
+        parity ^= 1;
+    }
     const int nf = min(FR, T - t0);         // frames this group owns
     if (EPI == 1 || (EPI == 3 && a.rows == PM_FFT_BINS)) {
         // a thread takes FOUR consecutive frames of one bin: one 16-byte store
@@ -592,7 +653,7 @@ void pm_stft_fft_kernel(FftArgs a) {
                     if (c + e < nf) dst[e] = src[e];
             }
         }
-    } else if constexpr (EPI == 5) {
+    } else if constexpr (EPI == 5 || EPI == 6) {
         float* ob = a.out + (size_t)b * 8 * T + t0;
         for (int idx = wtid; idx < 8 * FR; idx += NT) {
             const int band = idx / FR, c = idx % FR;

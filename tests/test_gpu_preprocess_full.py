@@ -212,6 +212,43 @@ def test_loudness_persistent_walk(device, cases, frames_per_group, shape):
     assert level.max() - level.min() > (25. if batch > 7 else 8.)
 
 
+@pytest.mark.parametrize('shape', ['full', 'ragged'])
+def test_optimistic_loudness_equals_two_passes(device, cases, frames_per_group,
+                                               shape):
+    """The opt-in optimistic schedule of the 8-band loudness
+    (pm_stft_set_loudness_passes(1)): the band means are written in the FIRST
+    pass, without a floor, and a 16-frame group is transformed again only where
+    a bin lies under the utterance's floor (pm_loudness, EPI 6 / EPI 5). Bit for
+    bit what the default two-transform schedule writes - on the test batches,
+    whose quiet stretches and zeroed tails DO sit on the floor (groups that are
+    redone) next to steady noise (groups that are not), and on a batch at one
+    steady level (nothing redone)."""
+    import promonet_amd
+    from promonet_amd import _lib
+    audio = cases[shape]['audio'].to(device)
+    steady = torch.randn(
+        4, 40 * 256 + 77, generator=torch.Generator().manual_seed(5)).to(device) * .1
+    try:
+        for signal in (audio, steady):
+            _lib.check(_lib.lib().pm_stft_set_loudness_passes(2))
+            two = promonet_amd.preprocess.loudness.from_audio(signal, 8)
+            _lib.check(_lib.lib().pm_stft_set_loudness_passes(1))
+            one = promonet_amd.preprocess.loudness.from_audio(signal, 8)
+            assert torch.equal(one, two)
+            assert torch.equal(
+                promonet_amd.preprocess.loudness.from_audio(signal, 8), one)
+        # (the floor really bites in the test batch: some band means differ
+        # from their unfloored values, i.e. groups WERE redone)
+        want = oracle.band_average(cases[shape]['loud'], 8)
+        assert ((one if signal is audio else two).shape[-1] > 0)
+        got = promonet_amd.preprocess.loudness.from_audio(audio, 8).cpu()
+        assert ((got - want).abs() <= 1e-4 + 1e-5 * want.abs()).all()
+    finally:
+        _lib.check(_lib.lib().pm_stft_set_loudness_passes(2))
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.lib().pm_stft_set_loudness_passes(3))
+
+
 def test_walk_equals_one_group_per_workgroup(device, cases):
     """Utterance 5 of the full batch alone (54 groups: one per workgroup) is
     bit-identical to its rows in the walked batch launch - the walk changes
